@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CLIP ViT-L/14 gallery encode (images + texts / s) and Q x 43k similarity + top-10 (ms).
+
+    python bench.py --gpus 1 --steps 8 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1] ("CLIP ViT-L/14 zero-shot, 43k gallery encode + T2I top-10 on 1xMI355X bf16"):
+one step = one gallery batch through the hot path exactly as the reference's eval loop encodes it
+(evaluator_baseline.py:100-121): `batch` images [B,3,224,224] + B query texts + B target texts -> three sets of
+L2-normalised embeddings, resident in HBM.  Synthetic inputs and seeded random-init weights of the ViT-L/14
+architecture (no network).  `value` = (images + texts) encoded per second over all ranks (weak scaling: every rank
+encodes its own `batch` gallery items per step).  After the timed region the same process measures
+  * the fused similarity + top-10 kernel on the 43k gallery (sharded over the ranks) for Q = 1024 and Q = 43000,
+  * per-kernel-class time with hipEvents on the launch stream (roofline of the dominant kernel, the bf16 GEMM),
+  * on rank 0 at N = 1: the CPU oracle on a bounded sample of the same workload (cpu_baseline).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from knowledge_enhanced_multimodal_retrieval_amd import _lib, engine  # noqa: E402
+from knowledge_enhanced_multimodal_retrieval_amd.config import ARCHS  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+GALLERY = 43000
+
+
+def random_weights(arch, seed=0):
+    """Seeded N(0, std) weights in OpenAI-CLIP naming (same shapes/stds as oracle.clip_ref.random_state_dict,
+    restated here so that the product path does not import the oracle)."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s, std: torch.randn(*s, generator=g) * std
+    sd = {}
+    vw, tw, D, p = arch.v_width, arch.t_width, arch.embed_dim, arch.patch
+    sd["visual.conv1.weight"] = rn(vw, 3, p, p, std=(3 * p * p) ** -0.5)
+    sd["visual.class_embedding"] = rn(vw, std=vw ** -0.5)
+    sd["visual.positional_embedding"] = rn(arch.v_tokens, vw, std=vw ** -0.5)
+    for nm in ("ln_pre", "ln_post"):
+        sd[f"visual.{nm}.weight"] = 1.0 + rn(vw, std=0.1)
+        sd[f"visual.{nm}.bias"] = rn(vw, std=0.1)
+    sd["visual.proj"] = rn(vw, D, std=vw ** -0.5)
+
+    def blocks(prefix, w, layers):
+        for i in range(layers):
+            b = f"{prefix}.resblocks.{i}"
+            sd[f"{b}.ln_1.weight"] = 1.0 + rn(w, std=0.1)
+            sd[f"{b}.ln_1.bias"] = rn(w, std=0.1)
+            sd[f"{b}.attn.in_proj_weight"] = rn(3 * w, w, std=w ** -0.5)
+            sd[f"{b}.attn.in_proj_bias"] = rn(3 * w, std=0.02)
+            sd[f"{b}.attn.out_proj.weight"] = rn(w, w, std=(w ** -0.5) * ((2 * layers) ** -0.5))
+            sd[f"{b}.attn.out_proj.bias"] = rn(w, std=0.02)
+            sd[f"{b}.ln_2.weight"] = 1.0 + rn(w, std=0.1)
+            sd[f"{b}.ln_2.bias"] = rn(w, std=0.1)
+            sd[f"{b}.mlp.c_fc.weight"] = rn(4 * w, w, std=(2 * w) ** -0.5)
+            sd[f"{b}.mlp.c_fc.bias"] = rn(4 * w, std=0.02)
+            sd[f"{b}.mlp.c_proj.weight"] = rn(w, 4 * w, std=(w ** -0.5) * ((2 * layers) ** -0.5))
+            sd[f"{b}.mlp.c_proj.bias"] = rn(w, std=0.02)
+
+    blocks("visual.transformer", vw, arch.v_layers)
+    sd["token_embedding.weight"] = rn(arch.vocab, tw, std=0.02)
+    sd["positional_embedding"] = rn(arch.ctx, tw, std=0.01)
+    blocks("transformer", tw, arch.t_layers)
+    sd["ln_final.weight"] = 1.0 + rn(tw, std=0.1)
+    sd["ln_final.bias"] = rn(tw, std=0.1)
+    sd["text_projection"] = rn(tw, D, std=tw ** -0.5)
+    return sd
+
+
+def synthetic_ids(arch, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.zeros(n, arch.ctx, dtype=torch.int32)
+    lens = torch.randint(8, arch.ctx, (n,), generator=g)
+    body = torch.randint(1, arch.sot, (n, arch.ctx), generator=g, dtype=torch.int32)
+    pos = torch.arange(arch.ctx)[None, :]
+    ids = torch.where(pos < lens[:, None], body, ids)
+    ids[:, 0] = arch.sot
+    ids[torch.arange(n), lens] = arch.eot
+    return ids
+
+
+def gemm_flops_per_step(arch, batch):
+    """Algorithmic FLOPs of the bf16 GEMM launches of one step (SURVEY.md 8(d) terms that run in gemm_bf16_nt_kernel)
+    and the number of launches."""
+    def tower(tokens, w, layers, items):
+        m = items * tokens
+        return 2.0 * m * layers * (w * 3 * w + w * w + 2 * w * 4 * w), 4 * layers
+    fi, li = tower(arch.v_tokens, arch.v_width, arch.v_layers, batch)
+    patch = 2.0 * batch * (arch.v_tokens - 1) * 3 * arch.patch * arch.patch * arch.v_width
+    ft, lt = tower(arch.ctx, arch.t_width, arch.t_layers, 2 * batch)   # flops of both text calls together
+    return fi + patch + ft, li + 1 + 2 * lt      # two encode_text calls (query, target) per step
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=255, help="gallery items per rank per step")
+    ap.add_argument("--model", default="ViT-L/14")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sim", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    arch = ARCHS[args.model]
+    B = args.batch
+    eng = engine.ClipEngine(arch, dev)
+    eng.load_state_dict(random_weights(arch, seed=0))
+
+    g = torch.Generator().manual_seed(1234 + rank)
+    pixels = torch.randn(B, 3, arch.image_size, arch.image_size, generator=g).to(dev)
+    q_ids = synthetic_ids(arch, B, 1235 + rank).to(dev)
+    t_ids = synthetic_ids(arch, B, 4321 + rank).to(dev)
+
+    def step():
+        a = eng.encode_image(pixels, normalize=True)
+        b = eng.encode_text(q_ids, normalize=True)
+        c = eng.encode_text(t_ids, normalize=True)
+        return a, b, c
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert all(torch.isfinite(o).all().item() for o in out)
+
+    items = 3 * B * world * args.steps                       # images + query texts + target texts
+    value = items / elapsed
+    flops_item_step = B * (arch.image_flops() + 2 * arch.text_flops())
+    result = {
+        "metric": "gallery images+texts encoded/sec (ViT-L/14) and 43k x Q sim+top-10 ms",
+        "value": value, "unit": "items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "CLIP ViT-L/14 zero-shot: 43k-gallery encode (1 image + query + target text per item, "
+                               "224x224 / 77 tokens) + T2I top-10, BASELINE configs[1]",
+                   "model": args.model, "batch_per_gpu": B, "gallery": GALLERY, "parallelism": f"dp{world} (gallery sharded)"},
+        "images_per_s": B * world * args.steps / elapsed,
+        "texts_per_s": 2 * B * world * args.steps / elapsed,
+        "encode_tflops_per_gpu": flops_item_step * args.steps / elapsed / 1e12,
+        "encode_frac_of_bf16_peak": flops_item_step * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS,
+    }
+
+    # ------------------------------------------------------------------ roofline: per-class hipEvent timing
+    L = _lib.lib()
+    prof_steps = 2
+    _lib.check(L.kemr_profile_begin(4096 * prof_steps))
+    for _ in range(prof_steps):
+        step()
+    ms = (C.c_double * 5)()
+    cnt = (C.c_int64 * 5)()
+    _lib.check(L.kemr_profile_end(ms, cnt, 5))
+    gemm_flops, _ = gemm_flops_per_step(arch, B)
+    gemm_ms, gemm_n = ms[0] / prof_steps, cnt[0] // prof_steps
+    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
+    result["roofline"] = {
+        "kernel": "gemm_bf16_nt_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
+        "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+        "launches_per_step": int(gemm_n), "avg_launch_us": 1e3 * gemm_ms / max(gemm_n, 1),
+        "flops_per_launch": gemm_flops / max(gemm_n, 1),
+    }
+    result["kernel_ms_per_step"] = {"gemm": ms[0] / prof_steps, "layernorm": ms[1] / prof_steps,
+                                    "attention": ms[2] / prof_steps, "embed_tail": ms[3] / prof_steps}
+
+    # ------------------------------------------------------------------ similarity + top-10 on the 43k gallery
+    if not args.no_sim:
+        per = (GALLERY + world - 1) // world
+        lo, hi = rank * per, min(GALLERY, (rank + 1) * per)
+        gg = torch.Generator(device=dev).manual_seed(7)
+        gal_all = torch.nn.functional.normalize(torch.randn(GALLERY, arch.embed_dim, generator=gg, device=dev), dim=-1)
+        qry_all = torch.nn.functional.normalize(gal_all + 0.04 * torch.randn(GALLERY, arch.embed_dim, generator=gg, device=dev), dim=-1)
+        sim = {}
+        for label, nq, terms in (("q1024_bf16", 1024, 1), ("q43000_bf16", GALLERY, 1), ("q43000_fp32x3", GALLERY, 3)):
+            gp = engine.build_panel([gal_all[lo:hi]], _lib.SIDE_GALLERY, terms)
+            qs = qry_all[:nq]
+
+            def run():
+                qp = engine.build_panel([qs], _lib.SIDE_QUERY, terms)   # queries arrive as fp32 embeddings
+                gt = torch.arange(nq, dtype=torch.int32, device=dev)
+                s, i = engine.sim_topk(qp, gp, 10, lo)
+                if dist is not None:                                   # exchange step: candidates of every shard, then merge
+                    ss = [torch.empty_like(s) for _ in range(world)]
+                    ii = [torch.empty_like(i) for _ in range(world)]
+                    dist.all_gather(ss, s)
+                    dist.all_gather(ii, i)
+                    s, i = engine.topk_merge(torch.stack(ss, 1), torch.stack(ii, 1), 10)
+                return s, i
+
+            run()
+            barrier()
+            reps = 5 if nq <= 2048 else 2
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                s, i = run()
+            barrier()
+            dt = (time.perf_counter() - t1) / reps
+            if dist is not None:
+                tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            flops = 2.0 * nq * GALLERY * arch.embed_dim * terms
+            sim[label] = {"ms": 1e3 * dt, "mfma_tflops_per_gpu": flops / dt / 1e12 / world,
+                          "top1_hit": float((i[:, 0].long() == torch.arange(nq, device=dev)).float().mean())}
+            del gp
+        result["sim_top10"] = sim
+
+    # ------------------------------------------------------------------ CPU baseline (oracle, bounded sample)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import clip_ref, metrics_ref
+        oa = clip_ref.ARCHS[args.model]
+        threads = torch.get_num_threads()
+        sd = random_weights(arch, seed=0)
+        n_img, n_txt = 6, 12
+        px = pixels[:n_img].cpu()
+        ids = torch.cat([q_ids[:n_txt // 2], t_ids[:n_txt // 2]]).cpu()
+        clip_ref.encode_text(sd, oa, ids[:2])                       # warm the allocator / thread pool
+        t1 = time.perf_counter()
+        ci = clip_ref.l2_normalize(clip_ref.encode_image(sd, oa, px))
+        ct = clip_ref.l2_normalize(clip_ref.encode_text(sd, oa, ids))
+        t_enc = time.perf_counter() - t1
+        # same mix as the GPU step: 1 image : 2 texts
+        t_img, t_txt = None, None
+        cpu_items_per_s = (n_img + n_txt) / t_enc
+        n_rank = 4096
+        im, qq, tt_ = metrics_ref.planted_embeddings(n_rank, arch.embed_dim, seed=0)
+        t1 = time.perf_counter()
+        metrics_ref.retrieval_metrics(qq, im, "T2I")
+        t_rank = time.perf_counter() - t1
+        cos = float(torch.nn.functional.cosine_similarity(out[0][:n_img].cpu().double(), ci.double()).min())
+        result["cpu_baseline"] = {
+            "value": cpu_items_per_s, "unit": "items/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/clip_ref fp32 torch on {threads} threads: {n_img} images + {n_txt} texts of the same "
+                      f"synthetic batch ({t_enc:.1f} s); oracle/metrics_ref sgemm + full argsort R@K/MRR at N={n_rank}: {t_rank:.2f} s",
+            "rank_metrics_n4096_s": t_rank, "gpu_vs_oracle_min_cosine_on_sample": cos,
+        }
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

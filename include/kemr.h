@@ -1,0 +1,196 @@
+/*
+ * kemr.h -- C ABI of libkemr.so, the MI355X (gfx950) CLIP retrieval hot path.
+ *
+ * The reference (REEVALUATE/knowledge_enhanced_multimodal_retrieval) is 100 % Python and has no
+ * native plugin/FFI boundary of its own: its boundary for this path is a set of Python call
+ * signatures.  This header is the C ABI one level below those signatures;
+ * every entry point names the reference call it replaces.  The Python host side
+ * (knowledge_enhanced_multimodal_retrieval_amd/, and the drop-in `src.clip.*` mirror) binds these
+ * symbols with ctypes; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain C: opaque handle, raw pointers, sizes; no torch / C++ types cross the ABI.
+ *  - every function returns KEMR_OK (0) or a negative kemr_status; kemr_last_error() returns a
+ *    thread-local message for the last failure.  Nothing throws across the ABI.
+ *  - "dev" pointers are device (HBM) pointers owned by the caller; the library never allocates on
+ *    the hot path.  Scratch comes from the caller through a workspace sized by *_workspace_bytes().
+ *    The library owns only the model handle and its packed weights (allocated in finalize).
+ *  - all launches are asynchronous on the hipStream_t passed as `void* stream` (0 = default stream);
+ *    no entry point synchronises the device except kemr_model_finalize().
+ *  - no HIP call happens at library load time (fork-safe for DataLoader workers,
+ *    reference: src/clip/eval/evaluator_baseline.py:83-92).
+ */
+#ifndef KEMR_H_
+#define KEMR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KEMR_ABI_VERSION 1
+
+typedef enum kemr_status {
+    KEMR_OK = 0,
+    KEMR_ERR_INVALID = -1,      /* bad argument / shape the kernels do not support */
+    KEMR_ERR_STATE = -2,        /* call order (e.g. encode before finalize, missing tensor) */
+    KEMR_ERR_HIP = -3,          /* a HIP runtime call failed; message carries hipGetErrorString */
+    KEMR_ERR_WORKSPACE = -4,    /* workspace too small / misaligned */
+    KEMR_ERR_NOMEM = -5
+} kemr_status;
+
+typedef enum kemr_dtype { KEMR_F32 = 0, KEMR_BF16 = 1, KEMR_I32 = 2 } kemr_dtype;
+
+/* compute precision of the encoder GEMMs (activations + weights); accumulation is always fp32 */
+typedef enum kemr_precision { KEMR_PREC_BF16 = 1 } kemr_precision;
+
+typedef enum kemr_tower { KEMR_TOWER_VISION = 0, KEMR_TOWER_TEXT = 1 } kemr_tower;
+
+/* Architecture numbers of an OpenAI-CLIP style model (heads are width/64, MLP is 4*width).
+ * ViT-L/14: {768,224,14,1024,24,768,12,49408,77}; ViT-B/32: {512,224,32,768,12,512,12,49408,77}. */
+typedef struct kemr_cfg {
+    int32_t embed_dim;    /* joint embedding size D */
+    int32_t image_size;   /* input resolution (square) */
+    int32_t patch;        /* patch size, image_size % patch == 0 */
+    int32_t v_width;      /* vision width, multiple of 256 */
+    int32_t v_layers;
+    int32_t t_width;      /* text width, multiple of 256 */
+    int32_t t_layers;
+    int32_t vocab;
+    int32_t ctx;          /* text context length (77) */
+} kemr_cfg;
+
+typedef struct kemr_model kemr_model;
+
+const char* kemr_last_error(void);
+int kemr_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Model lifecycle.  Replaces `clip.load(name, device)` + `.float()` + `load_state_dict(sd,
+ * strict=True)` (reference: src/clip/model/clip_model.py:41-64).
+ *   create -> load_tensor (once per state-dict entry, OpenAI-CLIP names, fp32 host memory)
+ *          -> finalize (checks every required tensor is present = "strict", packs bf16 weights
+ *             into device memory: q-scale folded into W_q, conv1 flattened/padded to a GEMM panel)
+ *   load_tensor may be called again after finalize (fine-tuned checkpoint): call finalize again.
+ * ------------------------------------------------------------------------------------------- */
+int kemr_model_create(const kemr_cfg* cfg, kemr_model** out);
+int kemr_model_load_tensor(kemr_model* m, const char* name, const void* host_ptr, int dtype /*kemr_dtype, F32 only*/,
+                           const int64_t* shape, int rank);
+int kemr_model_finalize(kemr_model* m, int precision /*kemr_precision*/);
+int kemr_model_destroy(kemr_model* m);
+/* number of required tensor names; name i via kemr_model_tensor_name (for strict-load diagnostics) */
+int kemr_model_num_tensors(const kemr_model* m);
+const char* kemr_model_tensor_name(const kemr_model* m, int i);
+
+/* ---------------------------------------------------------------------------------------------
+ * Encoders.  Replace `model.encode_image(images)` / `model.encode_text(tokens)` and the following
+ * `x / x.norm(dim=-1, keepdim=True)` (reference: src/clip/eval/evaluator_baseline.py:107-108,
+ * 113-114, 119-120; src/clip/eval/evaluator.py:121-122, 127-128, 133-134;
+ * src/clip/model/fusion_model.py:287-303).
+ *   pixels_dev : fp32 [B,3,S,S] contiguous NCHW, already mean/std normalised
+ *   ids_dev    : int32 [B,ctx]; pooled at the first position of the row maximum (EOT)
+ *   out_dev    : fp32 [B, embed_dim]; L2-normalised when normalize != 0
+ *   workspace  : >= kemr_workspace_bytes(m, tower, B) bytes, 256-byte aligned, contents don't matter
+ * ------------------------------------------------------------------------------------------- */
+size_t kemr_workspace_bytes(const kemr_model* m, int tower /*kemr_tower*/, int batch);
+int kemr_encode_image(kemr_model* m, const float* pixels_dev, int batch, float* out_dev, int normalize,
+                      void* workspace_dev, size_t workspace_bytes, void* stream);
+int kemr_encode_text(kemr_model* m, const int32_t* ids_dev, int batch, float* out_dev, int normalize,
+                     void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Similarity + ranking.  Replaces `S = Q @ C.T`, the weighted T2I/T2T sum, and the two full
+ * `np.argsort(-S)` passes of Recall@K / MRR (reference: src/clip/eval/metrics.py:13-76, 102,
+ * 145-148; src/clip/eval/fusion.py:6-20) without materialising the Q x N matrix.
+ *
+ * Operands are "panels": bf16 [rows, kdim] row-major with kdim % 64 == 0, built by
+ * kemr_panel_build from fp32 embeddings.  A panel concatenates `nparts` embedding sets along k
+ * (fused T2I+T2T scoring = one contraction over [w_i*I ; w_t*T], metrics.py:148) and, with
+ * terms == 3, stores the bf16 split hi/lo so that the contraction reproduces fp32 products
+ * (query panel [hi | lo | hi], gallery panel [hi | hi | lo]); terms == 1 is plain bf16.
+ *   kdim = nparts * terms * ceil64(D)
+ * A panel buffer must be allocated with its row count rounded up to a multiple of 128
+ * (kemr_panel_build zero-fills the pad rows; the kernels read whole 128-row tiles).
+ * ------------------------------------------------------------------------------------------- */
+typedef enum kemr_panel_side { KEMR_SIDE_QUERY = 0, KEMR_SIDE_GALLERY = 1 } kemr_panel_side;
+
+int64_t kemr_panel_kdim(int d, int nparts, int terms);
+/* parts[p] : fp32 [rows, d] dev pointers (nparts of them, host array of pointers);
+ * part_scale[p] : scalar weight applied to part p (NULL = 1); row_scale[p] : optional fp32 [rows]
+ * dev pointer with a per-row factor for part p (per-query gate, fusion_model.py:136-196), or NULL. */
+int kemr_panel_build(const float* const* parts_dev, const float* part_scale, const float* const* row_scale_dev,
+                     int nparts, int rows, int d, int terms, int side /*kemr_panel_side*/,
+                     void* panel_dev /* bf16 [rows, kdim] */, void* stream);
+
+/* Fused score + per-query top-k + rank of a ground-truth candidate.
+ *   q_panel [nq,kdim], g_panel [ng,kdim]
+ *   gallery_offset : global id of gallery row 0 (sharded galleries); ids written are global
+ *   k <= 32; top_scores/top_idx [nq,k] sorted (score desc, id asc), padded with -inf / -1
+ *   gt_idx  : optional int32 [nq] GLOBAL candidate id of each query's ground truth
+ *   gt_score: optional fp32 [nq]; score of (query, gt) as produced by kemr_pair_scores
+ *   ahead   : optional int32 [nq]; += #{j in this gallery : s_ij > s_gt or (s_ij == s_gt and id_j < gt)}
+ *             (rank = 1 + sum of `ahead` over shards; caller zeroes it)
+ *   bonus_*: optional sparse additive bonuses (SPARQL hits, eval/fusion.py:22-206) in CSR over
+ *            queries: bonus_rowptr int32 [nq+1], bonus_col int32 (GLOBAL ids, ascending within a row),
+ *            bonus_val fp32.  Weighted fusion's alpha is folded into the query panel (part_scale).
+ *   workspace >= kemr_sim_workspace_bytes(nq, ng, k) */
+size_t kemr_sim_workspace_bytes(int nq, int ng, int k);
+int kemr_sim_topk(const void* q_panel_dev, int nq, const void* g_panel_dev, int ng, int64_t kdim,
+                  int64_t gallery_offset, int k, float* top_scores_dev, int32_t* top_idx_dev,
+                  const int32_t* gt_idx_dev, const float* gt_score_dev, int32_t* ahead_dev,
+                  const int32_t* bonus_rowptr_dev, const int32_t* bonus_col_dev, const float* bonus_val_dev,
+                  void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* score of listed (query row, LOCAL gallery row) pairs with exactly the arithmetic of kemr_sim_topk
+ * (same MFMA k-order), so that `s_ij > s_gt` comparisons are self-consistent. out fp32 [npairs]. */
+int kemr_pair_scores(const void* q_panel_dev, const void* g_panel_dev, int64_t kdim,
+                     const int32_t* q_rows_dev, const int32_t* g_rows_dev, int npairs,
+                     float* out_dev, void* stream);
+
+/* Merge `nlists` sorted top-k lists per query (shards / column chunks) into one.
+ * in_scores/in_idx [nq, nlists, k] -> out [nq, k]; same order rule as kemr_sim_topk. */
+int kemr_topk_merge(const float* in_scores_dev, const int32_t* in_idx_dev, int nq, int nlists, int k,
+                    float* out_scores_dev, int32_t* out_idx_dev, void* stream);
+
+/* Dense score tile (for the learned fusion heads that are not GEMM epilogues and for debugging):
+ * out fp32 [nq, ng] row-major = q_panel . g_panel^T.  Reference: fusion_model.py:324-325. */
+int kemr_scores_dense(const void* q_panel_dev, int nq, const void* g_panel_dev, int ng, int64_t kdim,
+                      float* out_dev, int64_t ld_out, void* stream);
+
+/* Rank an already materialised score matrix (fp32 [nq, ld], device): for every row the number of
+ * candidates ranked ahead of column gt_idx[row] (written, not accumulated) and/or the sorted top-k.
+ * Replaces the np.argsort passes when the caller hands over a matrix: compute_recall_at_k,
+ * compute_mrr_and_mean_rank (metrics.py:13-76), compute_retrieval_metrics_fusion (metrics.py:165-185),
+ * evaluate_retrieval (eval/fusion.py:6-20), evaluator_fusion.py:126.  Either output pair may be NULL. */
+int kemr_rank_dense(const float* scores_dev, int nq, int ng, int64_t ld, const int32_t* gt_idx_dev,
+                    int32_t* ahead_dev, int k, float* top_scores_dev, int32_t* top_idx_dev, void* stream);
+
+/* Optional per-kernel-class timing with hipEvents recorded on the launch stream (bench.py's roofline line).
+ * Classes: 0 GEMM, 1 LayerNorm, 2 attention, 3 embed/tail, 4 similarity tile kernel.  Not thread-safe;
+ * profile_end synchronises the device.  Off by default: no events are recorded on the normal path. */
+#define KEMR_PROF_NCLASS 5
+int kemr_profile_begin(int max_launches);
+int kemr_profile_end(double* ms_per_class, int64_t* launches_per_class, int nclass);
+
+/* ---------------------------------------------------------------------------------------------
+ * Building blocks exposed for per-kernel parity tests (tests/ call these through the ABI).
+ * ------------------------------------------------------------------------------------------- */
+typedef enum kemr_epilogue {
+    KEMR_EPI_BIAS_BF16 = 0,        /* C_bf16 = A.W^T + bias                                  */
+    KEMR_EPI_BIAS_QGELU_BF16 = 1,  /* C_bf16 = quickgelu(A.W^T + bias)                       */
+    KEMR_EPI_BIAS_RESID_F32 = 2    /* X_f32 += A.W^T + bias   (in place on the residual)      */
+} kemr_epilogue;
+/* A bf16 [m_alloc, k] (m_alloc = m rounded up to 256 rows, readable), W bf16 [n, k], bias fp32 [n] */
+int kemr_op_gemm(const void* a_dev, const void* w_dev, const float* bias_dev, void* c_dev,
+                 int m, int n, int k, int epilogue, void* stream);
+int kemr_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, void* y_dev,
+                      int rows, int width, int out_dtype /*KEMR_BF16|KEMR_F32*/, void* stream);
+/* qkv bf16 [batch*t, 3*width] (q pre-scaled by 1/8) -> out bf16 [batch*t, width] */
+int kemr_op_attention(const void* qkv_dev, void* out_dev, int batch, int t, int width, int causal, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KEMR_H_ */

@@ -1,0 +1,93 @@
+"""ctypes binding of libkemr.so (C ABI declared in include/kemr.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  ``lib()`` raises if the shared object is
+missing or does not export every declared symbol, and every wrapper in this package raises
+``RuntimeError`` when a call returns a non-zero status.  Loading the library does not touch the GPU
+(no HIP call happens until a model is finalised or a kernel is launched), so importing this module is
+safe in forked DataLoader workers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libkemr.so")
+
+KEMR_F32, KEMR_BF16, KEMR_I32 = 0, 1, 2
+PREC_BF16 = 1
+TOWER_VISION, TOWER_TEXT = 0, 1
+SIDE_QUERY, SIDE_GALLERY = 0, 1
+EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RESID_F32 = 0, 1, 2
+
+
+class KemrCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("embed_dim", "image_size", "patch", "v_width", "v_layers",
+                                          "t_width", "t_layers", "vocab", "ctx")]
+
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/kemr.h declares (tests check this)
+SIGNATURES = {
+    "kemr_last_error": (C.c_char_p, []),
+    "kemr_abi_version": (_i, []),
+    "kemr_model_create": (_i, [C.POINTER(KemrCfg), C.POINTER(_vp)]),
+    "kemr_model_load_tensor": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(_i64), _i]),
+    "kemr_model_finalize": (_i, [_vp, _i]),
+    "kemr_model_destroy": (_i, [_vp]),
+    "kemr_model_num_tensors": (_i, [_vp]),
+    "kemr_model_tensor_name": (C.c_char_p, [_vp, _i]),
+    "kemr_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "kemr_encode_image": (_i, [_vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "kemr_encode_text": (_i, [_vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "kemr_panel_kdim": (_i64, [_i, _i, _i]),
+    "kemr_panel_build": (_i, [C.POINTER(_vp), C.POINTER(_f), C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp]),
+    "kemr_sim_workspace_bytes": (_sz, [_i, _i, _i]),
+    "kemr_sim_topk": (_i, [_vp, _i, _vp, _i, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kemr_pair_scores": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _vp, _vp]),
+    "kemr_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "kemr_scores_dense": (_i, [_vp, _i, _vp, _i, _i64, _vp, _i64, _vp]),
+    "kemr_rank_dense": (_i, [_vp, _i, _i, _i64, _vp, _vp, _i, _vp, _vp, _vp]),
+    "kemr_profile_begin": (_i, [_i]),
+    "kemr_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i64), _i]),
+    "kemr_op_gemm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "kemr_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "kemr_op_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libkemr.so once; raise (never fall back) when it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m knowledge_enhanced_multimodal_retrieval_amd.build` "
+                "(hipcc, gfx950). There is no CPU fallback for this path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
+            fn.restype = res
+            fn.argtypes = args
+        if handle.kemr_abi_version() != 1:
+            raise RuntimeError("libkemr.so ABI version mismatch; rebuild the library")
+        _lib = handle
+        return _lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = lib().kemr_last_error()
+        raise RuntimeError(f"libkemr {what} failed ({status}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,423 @@
+// libkemr.so: model handle, weight packing and the encoder launch sequences behind the C ABI (include/kemr.h).
+// Host-side C++ only; every kernel lives in gemm.hip / layernorm.hip / attention.hip / embed.hip / sim.hip.
+#include "common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace kemr {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- event profiler: off by default; bench.py turns it on for a few untimed-for-throughput steps ----
+struct ProfState {
+    bool on = false;
+    std::vector<hipEvent_t> ev;       // 2 per slot
+    std::vector<int> cls;
+    int used = 0;
+};
+static ProfState g_prof;
+
+ProfScope::ProfScope(int c, hipStream_t s) : slot(-1), stream(s) {
+    if (!g_prof.on || g_prof.used >= (int)g_prof.cls.size()) return;
+    slot = g_prof.used++;
+    g_prof.cls[slot] = c;
+    (void)hipEventRecord(g_prof.ev[2 * slot], stream);
+}
+ProfScope::~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], stream);
+}
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    bool loaded = false;
+};
+
+struct LayerW {
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *bqkv, *bo, *b1, *b2;
+    const bf16_t *wqkv, *wo, *w1, *w2;
+};
+
+struct TowerW {
+    int width = 0, layers = 0, tokens = 0;
+    std::vector<LayerW> layer;
+};
+
+}  // namespace kemr
+
+using namespace kemr;
+
+struct kemr_model {
+    kemr_cfg cfg;
+    std::vector<std::string> names;                 // required tensors, fixed order
+    std::map<std::string, HostTensor> tensors;
+    bool finalized = false;
+    char* arena = nullptr;                          // device weights
+    size_t arena_bytes = 0;
+    int grid = 0, patches = 0, kpad = 0;
+    // vision
+    TowerW vis;
+    const bf16_t* conv_w = nullptr;
+    const float *cls = nullptr, *vpos = nullptr, *lnpre_g = nullptr, *lnpre_b = nullptr, *lnpost_g = nullptr,
+                *lnpost_b = nullptr, *vproj = nullptr;
+    // text
+    TowerW txt;
+    const float *tok = nullptr, *tpos = nullptr, *lnf_g = nullptr, *lnf_b = nullptr, *tproj = nullptr;
+};
+
+namespace {
+
+void add_block_names(std::vector<std::string>& v, std::map<std::string, HostTensor>& t, const std::string& prefix,
+                     int width, int layers) {
+    auto add = [&](const std::string& n, std::vector<int64_t> shape) { v.push_back(n); t[n].shape = std::move(shape); };
+    for (int i = 0; i < layers; ++i) {
+        const std::string b = prefix + ".resblocks." + std::to_string(i);
+        add(b + ".ln_1.weight", {width});
+        add(b + ".ln_1.bias", {width});
+        add(b + ".attn.in_proj_weight", {3 * width, width});
+        add(b + ".attn.in_proj_bias", {3 * width});
+        add(b + ".attn.out_proj.weight", {width, width});
+        add(b + ".attn.out_proj.bias", {width});
+        add(b + ".ln_2.weight", {width});
+        add(b + ".ln_2.bias", {width});
+        add(b + ".mlp.c_fc.weight", {4 * width, width});
+        add(b + ".mlp.c_fc.bias", {4 * width});
+        add(b + ".mlp.c_proj.weight", {width, 4 * width});
+        add(b + ".mlp.c_proj.bias", {width});
+    }
+}
+
+int check_cfg(const kemr_cfg& c) {
+    if (c.embed_dim <= 0 || c.embed_dim > 1024) KEMR_FAIL(KEMR_ERR_INVALID, "cfg: embed_dim %d not in 1..1024", c.embed_dim);
+    if (c.patch <= 0 || c.image_size <= 0 || c.image_size % c.patch) KEMR_FAIL(KEMR_ERR_INVALID, "cfg: image_size %% patch != 0");
+    if (c.v_width % 256 || c.t_width % 256 || c.v_width <= 0 || c.t_width <= 0 || c.v_width > 1280 || c.t_width > 1280)
+        KEMR_FAIL(KEMR_ERR_INVALID, "cfg: widths must be multiples of 256 in 256..1280 (got %d, %d)", c.v_width, c.t_width);
+    if (c.v_layers <= 0 || c.t_layers <= 0 || c.vocab <= 0 || c.ctx <= 0) KEMR_FAIL(KEMR_ERR_INVALID, "cfg: non-positive field");
+    const int g = c.image_size / c.patch;
+    if (g * g + 1 > 288 || c.ctx > 288) KEMR_FAIL(KEMR_ERR_INVALID, "cfg: sequence length > 288 not supported");
+    const int kpad = (int)round_up(3 * c.patch * c.patch, 64);
+    if (kpad > 4 * c.v_width) KEMR_FAIL(KEMR_ERR_INVALID, "cfg: patch too large for the workspace layout");
+    return KEMR_OK;
+}
+
+struct ArenaPlan {
+    size_t bytes = 0;
+    size_t take(size_t n) { size_t o = bytes; bytes += (size_t)round_up((int64_t)n, 256); return o; }
+};
+
+}  // namespace
+
+extern "C" const char* kemr_last_error(void) { return g_err; }
+extern "C" int kemr_abi_version(void) { return KEMR_ABI_VERSION; }
+
+extern "C" int kemr_model_create(const kemr_cfg* cfg, kemr_model** out) {
+    if (!cfg || !out) KEMR_FAIL(KEMR_ERR_INVALID, "model_create: null argument");
+    KEMR_TRY(check_cfg(*cfg));
+    kemr_model* m = new (std::nothrow) kemr_model();
+    if (!m) KEMR_FAIL(KEMR_ERR_NOMEM, "model_create: out of memory");
+    m->cfg = *cfg;
+    m->grid = cfg->image_size / cfg->patch;
+    m->patches = m->grid * m->grid;
+    m->kpad = (int)round_up(3 * cfg->patch * cfg->patch, 64);
+    auto add = [&](const std::string& n, std::vector<int64_t> shape) { m->names.push_back(n); m->tensors[n].shape = std::move(shape); };
+    const int vw = cfg->v_width, tw = cfg->t_width, D = cfg->embed_dim;
+    add("visual.conv1.weight", {vw, 3, cfg->patch, cfg->patch});
+    add("visual.class_embedding", {vw});
+    add("visual.positional_embedding", {m->patches + 1, vw});
+    add("visual.ln_pre.weight", {vw});
+    add("visual.ln_pre.bias", {vw});
+    add_block_names(m->names, m->tensors, "visual.transformer", vw, cfg->v_layers);
+    add("visual.ln_post.weight", {vw});
+    add("visual.ln_post.bias", {vw});
+    add("visual.proj", {vw, D});
+    add("token_embedding.weight", {cfg->vocab, tw});
+    add("positional_embedding", {cfg->ctx, tw});
+    add_block_names(m->names, m->tensors, "transformer", tw, cfg->t_layers);
+    add("ln_final.weight", {tw});
+    add("ln_final.bias", {tw});
+    add("text_projection", {tw, D});
+    *out = m;
+    return KEMR_OK;
+}
+
+extern "C" int kemr_model_num_tensors(const kemr_model* m) { return m ? (int)m->names.size() : 0; }
+extern "C" const char* kemr_model_tensor_name(const kemr_model* m, int i) {
+    if (!m || i < 0 || i >= (int)m->names.size()) return nullptr;
+    return m->names[i].c_str();
+}
+
+extern "C" int kemr_model_load_tensor(kemr_model* m, const char* name, const void* host_ptr, int dtype,
+                                      const int64_t* shape, int rank) {
+    if (!m || !name || !host_ptr || (!shape && rank > 0)) KEMR_FAIL(KEMR_ERR_INVALID, "load_tensor: null argument");
+    if (dtype != KEMR_F32) KEMR_FAIL(KEMR_ERR_INVALID, "load_tensor(%s): only fp32 host tensors are accepted", name);
+    const std::string n(name);
+    if (n == "logit_scale" || n == "input_resolution" || n == "context_length" || n == "vocab_size") return KEMR_OK;  // not on the encode path
+    auto it = m->tensors.find(n);
+    if (it == m->tensors.end()) KEMR_FAIL(KEMR_ERR_INVALID, "load_tensor: unexpected key '%s' (strict load)", name);
+    HostTensor& t = it->second;
+    bool same = (int)t.shape.size() == rank;
+    int64_t numel = 1;
+    for (int i = 0; same && i < rank; ++i) same = t.shape[i] == shape[i];
+    if (!same) {
+        std::string want, got;
+        for (auto s : t.shape) want += std::to_string(s) + ",";
+        for (int i = 0; i < rank; ++i) got += std::to_string(shape[i]) + ",";
+        KEMR_FAIL(KEMR_ERR_INVALID, "load_tensor: size mismatch for %s: expected [%s] got [%s]", name, want.c_str(), got.c_str());
+    }
+    for (auto s : t.shape) numel *= s;
+    t.data.assign((const float*)host_ptr, (const float*)host_ptr + numel);
+    t.loaded = true;
+    m->finalized = false;
+    return KEMR_OK;
+}
+
+extern "C" int kemr_model_finalize(kemr_model* m, int precision) {
+    if (!m) KEMR_FAIL(KEMR_ERR_INVALID, "finalize: null model");
+    if (precision != KEMR_PREC_BF16) KEMR_FAIL(KEMR_ERR_INVALID, "finalize: unsupported precision %d", precision);
+    for (const auto& n : m->names)
+        if (!m->tensors[n].loaded) KEMR_FAIL(KEMR_ERR_STATE, "finalize: missing key '%s' (strict load)", n.c_str());
+
+    // plan the device arena: f32 tensors verbatim, matrices as bf16
+    ArenaPlan plan;
+    std::map<std::string, size_t> off;
+    auto is_matrix = [](const std::string& n) {
+        return n.find("in_proj_weight") != std::string::npos || n.find("out_proj.weight") != std::string::npos ||
+               n.find("c_fc.weight") != std::string::npos || n.find("c_proj.weight") != std::string::npos ||
+               n == "visual.conv1.weight";
+    };
+    for (const auto& n : m->names) {
+        const HostTensor& t = m->tensors[n];
+        size_t bytes;
+        if (n == "visual.conv1.weight") bytes = (size_t)m->cfg.v_width * m->kpad * 2;
+        else if (is_matrix(n)) bytes = t.data.size() * 2;
+        else bytes = t.data.size() * 4;
+        off[n] = plan.take(bytes);
+    }
+    std::vector<char> host(plan.bytes, 0);
+    for (const auto& n : m->names) {
+        const HostTensor& t = m->tensors[n];
+        char* dst = host.data() + off[n];
+        if (n == "visual.conv1.weight") {
+            const int kv = 3 * m->cfg.patch * m->cfg.patch;
+            bf16_t* d = (bf16_t*)dst;
+            for (int r = 0; r < m->cfg.v_width; ++r)
+                for (int k = 0; k < kv; ++k) d[(size_t)r * m->kpad + k] = f32_to_bf16_host(t.data[(size_t)r * kv + k]);
+        } else if (n.find("in_proj_weight") != std::string::npos) {
+            // fold the attention scale 1/sqrt(64) = 0.125 (exact in bf16) into the query rows
+            const int64_t w = t.shape[1];
+            bf16_t* d = (bf16_t*)dst;
+            for (int64_t i = 0; i < (int64_t)t.data.size(); ++i)
+                d[i] = f32_to_bf16_host(i < w * w ? t.data[i] * 0.125f : t.data[i]);
+        } else if (n.find("in_proj_bias") != std::string::npos) {
+            const int64_t w = t.shape[0] / 3;
+            float* d = (float*)dst;
+            for (int64_t i = 0; i < (int64_t)t.data.size(); ++i) d[i] = i < w ? t.data[i] * 0.125f : t.data[i];
+        } else if (is_matrix(n)) {
+            bf16_t* d = (bf16_t*)dst;
+            for (size_t i = 0; i < t.data.size(); ++i) d[i] = f32_to_bf16_host(t.data[i]);
+        } else {
+            memcpy(dst, t.data.data(), t.data.size() * 4);
+        }
+    }
+    if (m->arena && m->arena_bytes != plan.bytes) { (void)hipFree(m->arena); m->arena = nullptr; }
+    if (!m->arena) {
+        KEMR_CHECK_HIP(hipMalloc((void**)&m->arena, plan.bytes));
+        m->arena_bytes = plan.bytes;
+    }
+    KEMR_CHECK_HIP(hipDeviceSynchronize());   // nothing may still read the old weights
+    KEMR_CHECK_HIP(hipMemcpy(m->arena, host.data(), plan.bytes, hipMemcpyHostToDevice));
+
+    auto F = [&](const std::string& n) { return (const float*)(m->arena + off.at(n)); };
+    auto H = [&](const std::string& n) { return (const bf16_t*)(m->arena + off.at(n)); };
+    auto tower = [&](TowerW& tw, const std::string& prefix, int width, int layers, int tokens) {
+        tw.width = width; tw.layers = layers; tw.tokens = tokens;
+        tw.layer.resize(layers);
+        for (int i = 0; i < layers; ++i) {
+            const std::string b = prefix + ".resblocks." + std::to_string(i);
+            LayerW& L = tw.layer[i];
+            L.ln1_g = F(b + ".ln_1.weight"); L.ln1_b = F(b + ".ln_1.bias");
+            L.wqkv = H(b + ".attn.in_proj_weight"); L.bqkv = F(b + ".attn.in_proj_bias");
+            L.wo = H(b + ".attn.out_proj.weight"); L.bo = F(b + ".attn.out_proj.bias");
+            L.ln2_g = F(b + ".ln_2.weight"); L.ln2_b = F(b + ".ln_2.bias");
+            L.w1 = H(b + ".mlp.c_fc.weight"); L.b1 = F(b + ".mlp.c_fc.bias");
+            L.w2 = H(b + ".mlp.c_proj.weight"); L.b2 = F(b + ".mlp.c_proj.bias");
+        }
+    };
+    tower(m->vis, "visual.transformer", m->cfg.v_width, m->cfg.v_layers, m->patches + 1);
+    tower(m->txt, "transformer", m->cfg.t_width, m->cfg.t_layers, m->cfg.ctx);
+    m->conv_w = H("visual.conv1.weight");
+    m->cls = F("visual.class_embedding"); m->vpos = F("visual.positional_embedding");
+    m->lnpre_g = F("visual.ln_pre.weight"); m->lnpre_b = F("visual.ln_pre.bias");
+    m->lnpost_g = F("visual.ln_post.weight"); m->lnpost_b = F("visual.ln_post.bias");
+    m->vproj = F("visual.proj");
+    m->tok = F("token_embedding.weight"); m->tpos = F("positional_embedding");
+    m->lnf_g = F("ln_final.weight"); m->lnf_b = F("ln_final.bias"); m->tproj = F("text_projection");
+
+    for (auto& kv : m->tensors) { std::vector<float>().swap(kv.second.data); kv.second.loaded = false; }
+    m->finalized = true;
+    return KEMR_OK;
+}
+
+extern "C" int kemr_model_destroy(kemr_model* m) {
+    if (!m) return KEMR_OK;
+    if (m->arena) (void)hipFree(m->arena);
+    delete m;
+    return KEMR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ encoders
+namespace {
+
+struct Workspace {
+    float* x;       // [Mp, W] fp32 residual stream
+    bf16_t* h;      // [Mp, W] bf16: LayerNorm output / attention output (GEMM A operand)
+    bf16_t* big;    // [Mp, 4W] bf16: qkv (ld 3W), MLP hidden (ld 4W), im2col patches
+};
+
+size_t ws_bytes(int width, int tokens, int batch) {
+    const int64_t Mp = round_up((int64_t)batch * tokens, 256);
+    return (size_t)(round_up(Mp * width * 4, 256) + round_up(Mp * width * 2, 256) + round_up(Mp * width * 8, 256));
+}
+
+int carve(Workspace& w, void* base, size_t bytes, int width, int tokens, int batch) {
+    const size_t need = ws_bytes(width, tokens, batch);
+    if (!base || bytes < need) KEMR_FAIL(KEMR_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", bytes, need);
+    if ((uintptr_t)base % 256) KEMR_FAIL(KEMR_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    const int64_t Mp = round_up((int64_t)batch * tokens, 256);
+    char* p = (char*)base;
+    w.x = (float*)p; p += round_up(Mp * width * 4, 256);
+    w.h = (bf16_t*)p; p += round_up(Mp * width * 2, 256);
+    w.big = (bf16_t*)p;
+    return KEMR_OK;
+}
+
+int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, hipStream_t s) {
+    const int W = t.width, M = batch * t.tokens;
+    for (int l = 0; l < t.layers; ++l) {
+        const LayerW& L = t.layer[l];
+        KEMR_TRY(launch_layernorm(w.x, L.ln1_g, L.ln1_b, w.h, M, W, KEMR_BF16, s));
+        GemmParams g{};
+        g.M = M;
+        g.A = w.h; g.lda = W; g.W = L.wqkv; g.ldw = W; g.bias = L.bqkv; g.C = w.big; g.ldc = 3 * W; g.N = 3 * W; g.K = W;
+        KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+        KEMR_TRY(launch_attention(w.big, w.h, batch, t.tokens, W, causal, s));
+        g.A = w.h; g.lda = W; g.W = L.wo; g.ldw = W; g.bias = L.bo; g.C = w.x; g.ldc = W; g.N = W; g.K = W;
+        KEMR_TRY(launch_gemm(g, EPI_BIAS_RESID_F32, s));
+        KEMR_TRY(launch_layernorm(w.x, L.ln2_g, L.ln2_b, w.h, M, W, KEMR_BF16, s));
+        g.A = w.h; g.lda = W; g.W = L.w1; g.ldw = W; g.bias = L.b1; g.C = w.big; g.ldc = 4 * W; g.N = 4 * W; g.K = W;
+        KEMR_TRY(launch_gemm(g, EPI_BIAS_QGELU_BF16, s));
+        g.A = w.big; g.lda = 4 * W; g.W = L.w2; g.ldw = 4 * W; g.bias = L.b2; g.C = w.x; g.ldc = W; g.N = W; g.K = 4 * W;
+        KEMR_TRY(launch_gemm(g, EPI_BIAS_RESID_F32, s));
+    }
+    return KEMR_OK;
+}
+
+}  // namespace
+
+extern "C" size_t kemr_workspace_bytes(const kemr_model* m, int tower, int batch) {
+    if (!m || batch <= 0) return 0;
+    if (tower == KEMR_TOWER_VISION) return ws_bytes(m->cfg.v_width, m->patches + 1, batch);
+    if (tower == KEMR_TOWER_TEXT) return ws_bytes(m->cfg.t_width, m->cfg.ctx, batch);
+    return 0;
+}
+
+extern "C" int kemr_encode_image(kemr_model* m, const float* pixels_dev, int batch, float* out_dev, int normalize,
+                                 void* workspace_dev, size_t workspace_bytes, void* stream) {
+    if (!m || !pixels_dev || !out_dev) KEMR_FAIL(KEMR_ERR_INVALID, "encode_image: null argument");
+    if (!m->finalized) KEMR_FAIL(KEMR_ERR_STATE, "encode_image: model not finalized");
+    if (batch <= 0) return batch == 0 ? KEMR_OK : (set_error("encode_image: negative batch"), KEMR_ERR_INVALID);
+    if ((int64_t)batch * (m->patches + 1) > (1 << 24)) KEMR_FAIL(KEMR_ERR_INVALID, "encode_image: batch %d too large", batch);
+    hipStream_t s = (hipStream_t)stream;
+    const int W = m->cfg.v_width, T = m->patches + 1;
+    Workspace w;
+    KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, T, batch));
+    KEMR_TRY(launch_im2col(pixels_dev, w.big, batch, m->cfg.image_size, m->cfg.patch, m->kpad, s));
+    GemmParams g{};
+    g.A = w.big; g.lda = m->kpad; g.W = m->conv_w; g.ldw = m->kpad; g.bias = nullptr; g.C = w.x; g.ldc = W;
+    g.pos = m->vpos; g.patches = m->patches; g.M = batch * m->patches; g.N = W; g.K = m->kpad;
+    KEMR_TRY(launch_gemm(g, EPI_PATCH_F32, s));
+    KEMR_TRY(launch_cls_rows(w.x, m->cls, m->vpos, batch, T, W, s));
+    KEMR_TRY(launch_layernorm(w.x, m->lnpre_g, m->lnpre_b, w.x, batch * T, W, KEMR_F32, s));
+    KEMR_TRY(run_blocks(m->vis, w, batch, 0, s));
+    KEMR_TRY(launch_tail(w.x, nullptr, batch, T, W, m->lnpost_g, m->lnpost_b, m->vproj, m->cfg.embed_dim, normalize, out_dev, s));
+    return KEMR_OK;
+}
+
+extern "C" int kemr_encode_text(kemr_model* m, const int32_t* ids_dev, int batch, float* out_dev, int normalize,
+                                void* workspace_dev, size_t workspace_bytes, void* stream) {
+    if (!m || !ids_dev || !out_dev) KEMR_FAIL(KEMR_ERR_INVALID, "encode_text: null argument");
+    if (!m->finalized) KEMR_FAIL(KEMR_ERR_STATE, "encode_text: model not finalized");
+    if (batch <= 0) return batch == 0 ? KEMR_OK : (set_error("encode_text: negative batch"), KEMR_ERR_INVALID);
+    if ((int64_t)batch * m->cfg.ctx > (1 << 24)) KEMR_FAIL(KEMR_ERR_INVALID, "encode_text: batch %d too large", batch);
+    hipStream_t s = (hipStream_t)stream;
+    const int W = m->cfg.t_width, T = m->cfg.ctx;
+    Workspace w;
+    KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, T, batch));
+    KEMR_TRY(launch_text_embed(ids_dev, m->tok, m->tpos, w.x, batch, T, W, m->cfg.vocab, s));
+    KEMR_TRY(run_blocks(m->txt, w, batch, 1, s));
+    KEMR_TRY(launch_tail(w.x, ids_dev, batch, T, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s));
+    return KEMR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ event profiler
+extern "C" int kemr_profile_begin(int max_launches) {
+    if (max_launches <= 0 || max_launches > (1 << 20)) KEMR_FAIL(KEMR_ERR_INVALID, "profile_begin: bad max_launches");
+    if (g_prof.on) KEMR_FAIL(KEMR_ERR_STATE, "profile_begin: already profiling");
+    while ((int)g_prof.ev.size() < 2 * max_launches) {
+        hipEvent_t e;
+        KEMR_CHECK_HIP(hipEventCreate(&e));
+        g_prof.ev.push_back(e);
+    }
+    g_prof.cls.assign(max_launches, 0);
+    g_prof.used = 0;
+    g_prof.on = true;
+    return KEMR_OK;
+}
+
+extern "C" int kemr_profile_end(double* ms_per_class, int64_t* launches_per_class, int nclass) {
+    if (!g_prof.on) KEMR_FAIL(KEMR_ERR_STATE, "profile_end: not profiling");
+    g_prof.on = false;
+    if (!ms_per_class || !launches_per_class || nclass < PROF_NCLASS) KEMR_FAIL(KEMR_ERR_INVALID, "profile_end: need %d classes", PROF_NCLASS);
+    for (int i = 0; i < nclass; ++i) { ms_per_class[i] = 0; launches_per_class[i] = 0; }
+    KEMR_CHECK_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < g_prof.used; ++i) {
+        float ms = 0.f;
+        KEMR_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+        ms_per_class[g_prof.cls[i]] += ms;
+        launches_per_class[g_prof.cls[i]] += 1;
+    }
+    return KEMR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ per-kernel test hooks
+extern "C" int kemr_op_gemm(const void* a_dev, const void* w_dev, const float* bias_dev, void* c_dev, int m, int n, int k,
+                            int epilogue, void* stream) {
+    if (!a_dev || !w_dev || !c_dev) KEMR_FAIL(KEMR_ERR_INVALID, "op_gemm: null argument");
+    if (epilogue < 0 || epilogue > KEMR_EPI_BIAS_RESID_F32) KEMR_FAIL(KEMR_ERR_INVALID, "op_gemm: bad epilogue %d", epilogue);
+    GemmParams g{};
+    g.A = (const bf16_t*)a_dev; g.lda = k; g.W = (const bf16_t*)w_dev; g.ldw = k; g.bias = bias_dev; g.C = c_dev; g.ldc = n;
+    g.M = m; g.N = n; g.K = k;
+    return launch_gemm(g, epilogue, (hipStream_t)stream);
+}
+
+extern "C" int kemr_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, void* y_dev, int rows,
+                                 int width, int out_dtype, void* stream) {
+    if (!x_dev || !gamma_dev || !beta_dev || !y_dev) KEMR_FAIL(KEMR_ERR_INVALID, "op_layernorm: null argument");
+    return launch_layernorm(x_dev, gamma_dev, beta_dev, y_dev, rows, width, out_dtype, (hipStream_t)stream);
+}
+
+extern "C" int kemr_op_attention(const void* qkv_dev, void* out_dev, int batch, int t, int width, int causal, void* stream) {
+    if (!qkv_dev || !out_dev) KEMR_FAIL(KEMR_ERR_INVALID, "op_attention: null argument");
+    return launch_attention((const bf16_t*)qkv_dev, (bf16_t*)out_dev, batch, t, width, causal, (hipStream_t)stream);
+}

@@ -1,0 +1,170 @@
+// Multi-head self-attention for the CLIP towers (head dim 64; T = 257 / 197 / 50 non-causal, T = 77 causal).
+//
+// One 256-thread workgroup per (image or text, head).  The whole K and V of that head (T <= 288 keys,
+// 2 x 36 KB) sit in LDS; every wave owns 16-query tiles and, because T is short, keeps the full score
+// row in registers -- plain softmax, no online rescaling.  MFMA v_mfma_f32_16x16x32_bf16 throughout:
+//   S^T tile = K_tile . Q^T      (A = K rows from LDS, B = Q rows straight from HBM)  -> a lane holds
+//              4 consecutive keys of ONE query column, so row max / sum are 2 shuffles (xor 16, 32);
+//   O^T      = V^T . P^T         (A = V^T fragment by ds_read_b64_tr_b16 from the row-major V image,
+//                                 B = P^T fragment = the score registers, converted to bf16 in place).
+// The k-slot order of the second product is permuted (slot 8*lq+j <-> key 32u + 16*(j>>2) + 4*lq + (j&3))
+// identically for both operands, which is what lets P feed the MFMA without any lane movement.
+// LDS images: K rows of 128 B with chunk ^= (row>>1)&7 (conflict-free ds_read_b128), V rows of 128 B
+// with 32-byte-chunk ^= (row>>1)&3 (conflict-free transposed reads).  Pad keys are zero-filled and masked.
+// The 1/sqrt(64) scale is folded into W_q / b_q when the weights are packed (exact: a power of two).
+#include "common.h"
+
+namespace kemr {
+
+__device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
+    typedef __attribute__((ext_vector_type(4))) short s4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)p);
+}
+
+template <int NT32, bool CAUSAL>   // keys padded to NT32 * 32
+__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                        int T, int width) {
+    constexpr int TP = NT32 * 32;
+    constexpr int NT16 = NT32 * 2;
+    constexpr float LOG2E = 1.4426950408889634f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = smem + TP * 128;
+
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ld = 3 * width;
+    const bf16_t* base = qkv + (size_t)b * T * ld + h * 64;
+
+    for (int idx = tid; idx < TP * 8; idx += 256) {
+        const int row = idx >> 3, c = idx & 7;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (row < T) {
+            kv = *(const uint4*)(base + (size_t)row * ld + width + c * 8);
+            vv = *(const uint4*)(base + (size_t)row * ld + 2 * width + c * 8);
+        }
+        *(uint4*)(sK + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kv;
+        *(uint4*)(sV + row * 128 + ((c ^ (((row >> 1) & 3) << 1)) << 4)) = vv;
+    }
+    __syncthreads();
+
+    const int lrow = lane & 15, lq = lane >> 4;
+    const int nqt = (T + 15) >> 4;
+    for (int qt = wid; qt < nqt; qt += 4) {            // wave-uniform trip count: EXEC stays full for the tr reads
+        const int q = qt * 16 + lrow;
+        const int qc = q < T ? q : T - 1;
+        bf16x8 qf[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const bf16x8*)(base + (size_t)qc * ld + kk * 32 + lq * 8);
+
+        f32x4 s[NT16];
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + lrow) * 128 + (((kk * 4 + lq) ^ (lrow >> 1)) << 4));
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
+            }
+        }
+        // s[t][r] = S[query lrow][key t*16 + lq*4 + r]
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = t * 16 + lq * 4 + r;
+                const bool ok = key < T && (!CAUSAL || key <= q);
+                s[t][r] = ok ? s[t][r] : -INFINITY;
+                mx = fmaxf(mx, s[t][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[t][r] = exp2f((s[t][r] - mx) * LOG2E);
+                sum += s[t][r];
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NT32; ++u) {
+            union { bf16x8 v; uint32_t w[4]; } pf;
+            pf.w[0] = pack_bf16x2(s[2 * u][0], s[2 * u][1]);
+            pf.w[1] = pack_bf16x2(s[2 * u][2], s[2 * u][3]);
+            pf.w[2] = pack_bf16x2(s[2 * u + 1][0], s[2 * u + 1][1]);
+            pf.w[3] = pack_bf16x2(s[2 * u + 1][2], s[2 * u + 1][3]);
+            const int ra = u * 32 + lq * 4 + (lrow >> 2);       // rows 32u + 4lq .. +3 (first half of the k slots)
+            const int rb = ra + 16;                             // rows 32u + 16 + 4lq .. +3
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int c = dt * 2 + ((lrow & 3) >> 1);
+                const bf16x4 va = lds_read_tr16(sV + ra * 128 + ((c ^ (((ra >> 1) & 3) << 1)) << 4) + (lrow & 1) * 8);
+                const bf16x4 vb = lds_read_tr16(sV + rb * 128 + ((c ^ (((rb >> 1) & 3) << 1)) << 4) + (lrow & 1) * 8);
+                bf16x8 vf;
+                vf[0] = va[0]; vf[1] = va[1]; vf[2] = va[2]; vf[3] = va[3];
+                vf[4] = vb[0]; vf[5] = vb[1]; vf[6] = vb[2]; vf[7] = vb[3];
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf.v, o[dt], 0, 0, 0);
+            }
+        }
+        // o[dt][r] = O[query lrow][d = dt*16 + lq*4 + r]
+        if (q < T) {
+            const float inv = 1.0f / sum;
+            bf16_t* dst = out + ((size_t)b * T + q) * width + h * 64 + lq * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 pk;
+                pk.x = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
+                pk.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
+                *(uint2*)(dst + dt * 16) = pk;
+            }
+        }
+    }
+}
+
+template <int NT32>
+static int launch_nt(const bf16_t* qkv, bf16_t* out, int batch, int t, int width, int causal, hipStream_t stream) {
+    constexpr int smem = NT32 * 32 * 128 * 2;
+    const dim3 grid(width / 64, batch);
+    ProfScope prof(PROF_ATTENTION, stream);
+    if (causal) {
+        auto kern = attention_kernel<NT32, true>;
+        KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, qkv, out, t, width);
+    } else {
+        auto kern = attention_kernel<NT32, false>;
+        KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, qkv, out, t, width);
+    }
+    KEMR_CHECK_LAUNCH("attention_kernel");
+    return KEMR_OK;
+}
+
+int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int t, int width, int causal, hipStream_t stream) {
+    if (batch <= 0) return KEMR_OK;
+    if (width % 64 != 0 || t <= 0) KEMR_FAIL(KEMR_ERR_INVALID, "attention: bad shape t=%d width=%d", t, width);
+    if (batch > 65535) KEMR_FAIL(KEMR_ERR_INVALID, "attention: batch %d > 65535", batch);
+    const int nt32 = (t + 31) / 32;
+    switch (nt32) {
+        case 1: return launch_nt<1>(qkv, out, batch, t, width, causal, stream);
+        case 2: return launch_nt<2>(qkv, out, batch, t, width, causal, stream);
+        case 3: return launch_nt<3>(qkv, out, batch, t, width, causal, stream);
+        case 4: return launch_nt<4>(qkv, out, batch, t, width, causal, stream);
+        case 5: return launch_nt<5>(qkv, out, batch, t, width, causal, stream);
+        case 6: return launch_nt<6>(qkv, out, batch, t, width, causal, stream);
+        case 7: return launch_nt<7>(qkv, out, batch, t, width, causal, stream);
+        case 8: return launch_nt<8>(qkv, out, batch, t, width, causal, stream);
+        case 9: return launch_nt<9>(qkv, out, batch, t, width, causal, stream);
+    }
+    KEMR_FAIL(KEMR_ERR_INVALID, "attention: sequence length %d > 288 not supported", t);
+}
+
+}  // namespace kemr

@@ -1,0 +1,94 @@
+// Shared declarations for libkemr.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/kemr.h"
+
+namespace kemr {
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA A/B fragment: 8 bf16 = 4 VGPRs
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;    // MFMA 16x16 C/D fragment
+
+// ---- error plumbing (thread-local message, never throws) -----------------------------------
+void set_error(const char* fmt, ...);
+#define KEMR_FAIL(code, ...) do { ::kemr::set_error(__VA_ARGS__); return (code); } while (0)
+#define KEMR_CHECK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    ::kemr::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    return KEMR_ERR_HIP; } } while (0)
+#define KEMR_CHECK_LAUNCH(what) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
+    ::kemr::set_error("launch of %s failed: %s (%s:%d)", what, hipGetErrorString(e_), __FILE__, __LINE__); \
+    return KEMR_ERR_HIP; } } while (0)
+#define KEMR_TRY(expr) do { int r_ = (expr); if (r_ != KEMR_OK) return r_; } while (0)
+
+// ---- host helpers ---------------------------------------------------------------------------
+static inline uint16_t f32_to_bf16_host(float f) {
+    uint32_t u; __builtin_memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);                 // round to nearest even
+}
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- device helpers -------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+// RNE; inputs on this path are finite (a NaN would come out as NaN-or-inf, MI355X_MICROARCH "Correctness boundaries")
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---- optional per-kernel-class event timing (api.hip); used by bench.py for the roofline line --------
+enum ProfClass : int { PROF_GEMM = 0, PROF_LAYERNORM = 1, PROF_ATTENTION = 2, PROF_OTHER = 3, PROF_SIM = 4, PROF_NCLASS = 5 };
+struct ProfScope {            // records a start/stop hipEvent pair on `s` when profiling is enabled
+    ProfScope(int cls, hipStream_t s);
+    ~ProfScope();
+    int slot; hipStream_t stream;
+};
+
+// ---- GEMM launcher (gemm.hip) -----------------------------------------------------------------
+enum GemmEpi : int {
+    EPI_BIAS_BF16 = KEMR_EPI_BIAS_BF16,
+    EPI_BIAS_QGELU_BF16 = KEMR_EPI_BIAS_QGELU_BF16,
+    EPI_BIAS_RESID_F32 = KEMR_EPI_BIAS_RESID_F32,
+    EPI_PATCH_F32 = 3,     // X_f32[remap(m)] = acc + pos[1 + m % tokens_per_img]   (patch embedding)
+};
+struct GemmParams {
+    const bf16_t* A;     // [m_alloc, lda] bf16, K contiguous
+    const bf16_t* W;     // [N, ldw] bf16, K contiguous (PyTorch Linear layout)
+    const float* bias;   // [N] or nullptr
+    void* C;             // bf16 [m_alloc, ldc] or fp32 [*, ldc] depending on the epilogue
+    const float* pos;    // EPI_PATCH_F32: positional embedding [1 + patches, N]
+    int M, N, K;         // M = valid rows (stores are guarded), N % 128 == 0, K % 64 == 0
+    int lda, ldw, ldc;
+    int patches;         // EPI_PATCH_F32: patches per image (row remap m -> m + m / patches + 1)
+};
+int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
+
+// ---- other launchers --------------------------------------------------------------------------
+int launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int rows, int width,
+                     int out_dtype, hipStream_t stream);
+int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int t, int width, int causal, hipStream_t stream);
+int launch_im2col(const float* pixels, bf16_t* patches, int batch, int image_size, int patch, int kpad, hipStream_t stream);
+int launch_cls_rows(float* x, const float* class_emb, const float* pos, int batch, int tokens, int width, hipStream_t stream);
+int launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos, float* x, int batch, int ctx,
+                      int width, int vocab, hipStream_t stream);
+// pooled row -> LayerNorm -> @ proj [width, d] -> optional L2 normalise.  ids == nullptr: row = b * tokens (CLS)
+int launch_tail(const float* x, const int32_t* ids, int batch, int tokens, int width, const float* gamma,
+                const float* beta, const float* proj, int d, int normalize, float* out, hipStream_t stream);
+
+}  // namespace kemr

@@ -1,0 +1,178 @@
+// Token assembly and pooling tail of the CLIP towers (HBM-bound element-wise work, fused where it is free).
+//   im2col      : NCHW fp32 pixels -> bf16 patch rows [B*P, kpad] so that the patch-embedding conv is a GEMM
+//                 (k = c*p*p + dy*p + dx, zero-padded to a multiple of 64); the GEMM epilogue adds the positional
+//                 embedding and scatters to token rows (gemm.hip, EPI_PATCH_F32).
+//   cls_rows    : token 0 of every image = class_embedding + positional_embedding[0].
+//   text_embed  : token_embedding[ids] + positional_embedding.
+//   tail        : pooled row (CLS, or the first arg-max of the ids = EOT) -> LayerNorm -> @ proj (fp32 weights)
+//                 -> optional L2 normalisation, one workgroup per output row.
+#include "common.h"
+
+namespace kemr {
+
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ px, bf16_t* __restrict__ out,
+                                                     int image_size, int patch, int grid, int kpad, int kvalid,
+                                                     long long total_pairs) {
+    // one thread per pair of adjacent k (patch is even for every CLIP model; odd patch handled element-wise)
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total_pairs) return;
+    const int kp2 = kpad >> 1;
+    const long long row = gid / kp2;
+    const int k = (int)(gid - row * kp2) * 2;
+    const int P = grid * grid;
+    const int b = (int)(row / P), pi = (int)(row - (long long)b * P);
+    const int py = pi / grid, pxi = pi - py * grid;
+    float v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int kk = k + e;
+        if (kk < kvalid) {
+            const int c = kk / (patch * patch), rem = kk - c * patch * patch;
+            const int dy = rem / patch, dx = rem - dy * patch;
+            v[e] = px[(((size_t)b * 3 + c) * image_size + (py * patch + dy)) * image_size + pxi * patch + dx];
+        } else {
+            v[e] = 0.f;
+        }
+    }
+    *(uint32_t*)(out + (size_t)row * kpad + k) = pack_bf16x2(v[0], v[1]);
+}
+
+int launch_im2col(const float* pixels, bf16_t* patches, int batch, int image_size, int patch, int kpad, hipStream_t stream) {
+    const int grid = image_size / patch;
+    const long long pairs = (long long)batch * grid * grid * (kpad / 2);
+    if (pairs <= 0) return KEMR_OK;
+    const long long blocks = (pairs + 255) / 256;
+    if (blocks > 0x7fffffffLL) KEMR_FAIL(KEMR_ERR_INVALID, "im2col: batch too large");
+    ProfScope prof(PROF_OTHER, stream);
+    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, pixels, patches, image_size, patch,
+                       grid, kpad, 3 * patch * patch, pairs);
+    KEMR_CHECK_LAUNCH("im2col_kernel");
+    return KEMR_OK;
+}
+
+__global__ __launch_bounds__(256) void cls_rows_kernel(float* __restrict__ x, const float* __restrict__ cls,
+                                                       const float* __restrict__ pos, int tokens, int width) {
+    const int b = blockIdx.x;
+    float* dst = x + (size_t)b * tokens * width;
+    for (int i = threadIdx.x; i < width; i += 256) dst[i] = cls[i] + pos[i];
+}
+
+int launch_cls_rows(float* x, const float* class_emb, const float* pos, int batch, int tokens, int width, hipStream_t stream) {
+    if (batch <= 0) return KEMR_OK;
+    ProfScope prof(PROF_OTHER, stream);
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(batch), dim3(256), 0, stream, x, class_emb, pos, tokens, width);
+    KEMR_CHECK_LAUNCH("cls_rows_kernel");
+    return KEMR_OK;
+}
+
+__global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids, const float* __restrict__ tok,
+                                                         const float* __restrict__ pos, float* __restrict__ x,
+                                                         int ctx, int width, int vocab, long long total4) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total4) return;
+    const int w4 = width >> 2;
+    const long long row = gid / w4;
+    const int c4 = (int)(gid - row * w4);
+    const int t = (int)(row % ctx);
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // out-of-range ids are clamped (torch would raise)
+    const float4 a = ((const float4*)(tok + (size_t)id * width))[c4];
+    const float4 p = ((const float4*)(pos + (size_t)t * width))[c4];
+    ((float4*)(x + (size_t)row * width))[c4] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+}
+
+int launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos, float* x, int batch, int ctx,
+                      int width, int vocab, hipStream_t stream) {
+    const long long total4 = (long long)batch * ctx * (width / 4);
+    if (total4 <= 0) return KEMR_OK;
+    ProfScope prof(PROF_OTHER, stream);
+    hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, ids, tok_emb, pos,
+                       x, ctx, width, vocab, total4);
+    KEMR_CHECK_LAUNCH("text_embed_kernel");
+    return KEMR_OK;
+}
+
+// block-wide sum over 256 threads; red must hold 4 floats; all threads get the result
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ x, const int32_t* __restrict__ ids,
+                                                   int tokens, int width, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, const float* __restrict__ proj,
+                                                   int d, int normalize, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* y = (float*)smem;          // [width] normalised row
+    float* red = y + width;           // [4]
+    int* pool = (int*)(red + 4);      // [1]
+    const int b = blockIdx.x, tid = threadIdx.x;
+
+    if (tid < 64) {
+        int best_t = 0;
+        if (ids) {                    // first position of the row maximum (torch.argmax semantics)
+            int best_v = INT_MIN;
+            for (int t = tid; t < tokens; t += 64) {
+                const int v = ids[(size_t)b * tokens + t];
+                if (v > best_v) { best_v = v; best_t = t; }
+            }
+            if (best_v == INT_MIN) best_t = INT_MAX;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const int ov = __shfl_xor(best_v, o), ot = __shfl_xor(best_t, o);
+                if (ov > best_v || (ov == best_v && ot < best_t)) { best_v = ov; best_t = ot; }
+            }
+        }
+        if (tid == 0) *pool = best_t;
+    }
+    __syncthreads();
+    const float* xr = x + ((size_t)b * tokens + *pool) * width;
+
+    float s = 0.f;
+    for (int i = tid; i < width; i += 256) s += xr[i];
+    const float mean = block_sum(s, red) / width;
+    float q = 0.f;
+    for (int i = tid; i < width; i += 256) { const float c = xr[i] - mean; q += c * c; }
+    const float rstd = 1.0f / sqrtf(block_sum(q, red) / width + 1e-5f);
+    for (int i = tid; i < width; i += 256) y[i] = (xr[i] - mean) * rstd * gamma[i] + beta[i];
+    __syncthreads();
+
+    // out[j] = sum_i y[i] * proj[i][j]; threads walk j (coalesced proj reads), up to 4 outputs per thread
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < width; ++i) {
+        const float yi = y[i];
+        const float* pr = proj + (size_t)i * d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = tid + e * 256;
+            if (j < d) acc[e] = fmaf(yi, pr[j], acc[e]);
+        }
+    }
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sq += acc[e] * acc[e];
+    const float nrm = sqrtf(block_sum(sq, red));
+    const float scale = normalize ? 1.0f / nrm : 1.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = tid + e * 256;
+        if (j < d) out[(size_t)b * d + j] = acc[e] * scale;
+    }
+}
+
+int launch_tail(const float* x, const int32_t* ids, int batch, int tokens, int width, const float* gamma,
+                const float* beta, const float* proj, int d, int normalize, float* out, hipStream_t stream) {
+    if (batch <= 0) return KEMR_OK;
+    if (d > 1024) KEMR_FAIL(KEMR_ERR_INVALID, "tail: embed_dim %d > 1024", d);
+    const size_t smem = (size_t)width * 4 + 32;
+    ProfScope prof(PROF_OTHER, stream);
+    hipLaunchKernelGGL(tail_kernel, dim3(batch), dim3(256), smem, stream, x, ids, tokens, width, gamma, beta, proj, d,
+                       normalize, out);
+    KEMR_CHECK_LAUNCH("tail_kernel");
+    return KEMR_OK;
+}
+
+}  // namespace kemr

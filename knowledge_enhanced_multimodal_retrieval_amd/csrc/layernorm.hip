@@ -1,0 +1,78 @@
+// LayerNorm over the residual stream: fp32 rows in, bf16 (GEMM operand) or fp32 (ln_pre, in place) out.
+// HBM-bound: one wave per row, the whole row lives in registers (float4 loads, 16 B / lane), mean and
+// variance by wave shuffles (two-pass, like torch's fp32 LayerNorm), 8-byte bf16 stores.
+// Algorithmic bytes per row: width * (4 read + 2 written) [+ 8 * width once for gamma/beta, L2-resident].
+#include "common.h"
+
+namespace kemr {
+
+template <int NV, typename OutT>   // width = NV * 256
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, OutT* y, int rows, float eps) {
+    constexpr int W = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4* xr = (const float4*)(x + (size_t)row * W);
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = xr[i * 64 + lane];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) * (1.0f / W);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / W) + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 g = ((const float4*)gamma)[i * 64 + lane];
+        const float4 b = ((const float4*)beta)[i * 64 + lane];
+        float4 o;
+        o.x = v[i].x * rstd * g.x + b.x;
+        o.y = v[i].y * rstd * g.y + b.y;
+        o.z = v[i].z * rstd * g.z + b.z;
+        o.w = v[i].w * rstd * g.w + b.w;
+        if constexpr (sizeof(OutT) == 2) {
+            uint2 pk;
+            pk.x = pack_bf16x2(o.x, o.y);
+            pk.y = pack_bf16x2(o.z, o.w);
+            ((uint2*)((bf16_t*)y + (size_t)row * W))[i * 64 + lane] = pk;
+        } else {
+            ((float4*)((float*)y + (size_t)row * W))[i * 64 + lane] = o;
+        }
+    }
+}
+
+template <int NV>
+static int launch_nv(const float* x, const float* g, const float* b, void* y, int rows, int out_dtype, hipStream_t s) {
+    const int blocks = (rows + 3) / 4;
+    ProfScope prof(PROF_LAYERNORM, s);
+    if (out_dtype == KEMR_BF16)
+        hipLaunchKernelGGL((layernorm_kernel<NV, bf16_t>), dim3(blocks), dim3(256), 0, s, x, g, b, (bf16_t*)y, rows, 1e-5f);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<NV, float>), dim3(blocks), dim3(256), 0, s, x, g, b, (float*)y, rows, 1e-5f);
+    KEMR_CHECK_LAUNCH("layernorm_kernel");
+    return KEMR_OK;
+}
+
+int launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int rows, int width,
+                     int out_dtype, hipStream_t stream) {
+    if (rows <= 0) return KEMR_OK;
+    if (out_dtype != KEMR_BF16 && out_dtype != KEMR_F32) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: bad out dtype %d", out_dtype);
+    switch (width) {
+        case 256:  return launch_nv<1>(x, gamma, beta, y, rows, out_dtype, stream);
+        case 512:  return launch_nv<2>(x, gamma, beta, y, rows, out_dtype, stream);
+        case 768:  return launch_nv<3>(x, gamma, beta, y, rows, out_dtype, stream);
+        case 1024: return launch_nv<4>(x, gamma, beta, y, rows, out_dtype, stream);
+        case 1280: return launch_nv<5>(x, gamma, beta, y, rows, out_dtype, stream);
+    }
+    KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: width %d not in {256,512,768,1024,1280}", width);
+}
+
+}  // namespace kemr

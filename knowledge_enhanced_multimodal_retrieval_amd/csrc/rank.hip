@@ -1,0 +1,120 @@
+// Ranking of an already materialised score matrix (HBM-bound, one streaming pass).
+// Serves the reference entry points that are handed a dense [Q, N] matrix instead of embeddings:
+// compute_recall_at_k / compute_mrr_and_mean_rank (metrics.py:13-76), compute_retrieval_metrics_fusion
+// (metrics.py:165-185), evaluate_retrieval (eval/fusion.py:6-20) and the learned-fusion evaluator
+// (eval/evaluator_fusion.py:126).  One 256-thread workgroup per query row: 16-byte loads where the row is
+// aligned, per-thread `ahead` count + sorted top-KMAX list in registers, then a k-round selection over the
+// 256 lists through LDS.  Algorithmic bytes: 4 * N per row.
+#include "common.h"
+
+namespace kemr {
+
+__device__ __forceinline__ bool rank_before(float sa, int ia, float sb, int ib) {
+    return sa > sb || (sa == sb && ia < ib);
+}
+
+template <int KMAX>
+__device__ __forceinline__ void list_insert(float (&s)[KMAX], int (&id)[KMAX], float v, int idx) {
+#pragma unroll
+    for (int i = KMAX - 1; i > 0; --i) {
+        const bool shift = v > s[i - 1];
+        const bool here = !shift && v > s[i];
+        s[i] = shift ? s[i - 1] : (here ? v : s[i]);
+        id[i] = shift ? id[i - 1] : (here ? idx : id[i]);
+    }
+    if (v > s[0]) { s[0] = v; id[0] = idx; }
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void rank_dense_kernel(const float* __restrict__ S, long long ld, int nq, int ng,
+                                                         const int32_t* __restrict__ gt_idx, int32_t* __restrict__ ahead,
+                                                         int k, float* __restrict__ top_s, int32_t* __restrict__ top_i) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = (float*)smem;                 // [256][KMAX]
+    int* xi = (int*)(xs + 256 * KMAX);        // [256][KMAX]
+    int* red = xi + 256 * KMAX;               // [4]
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const float* row = S + (size_t)q * ld;
+    const int gt = gt_idx ? gt_idx[q] : -1;
+    const bool has_gt = gt >= 0 && gt < ng;
+    const float sgt = has_gt ? row[gt] : 0.f;
+    float ls[KMAX];
+    int li[KMAX];
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) { ls[i] = -INFINITY; li[i] = -1; }
+    int cnt = 0;
+    // a thread's candidate ids increase monotonically, so strict '>' keeps "lower id first" inside its list
+    for (int j = tid; j < ng; j += 256) {
+        const float v = row[j];
+        if (has_gt && j != gt) cnt += rank_before(v, j, sgt, gt) ? 1 : 0;
+        if (top_s && v > ls[KMAX - 1]) list_insert<KMAX>(ls, li, v, j);
+    }
+    if (ahead && has_gt) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (lane == 0) red[tid >> 6] = cnt;
+    }
+    if (top_s) {
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) { xs[tid * KMAX + i] = ls[i]; xi[tid * KMAX + i] = li[i]; }
+    }
+    __syncthreads();
+    if (ahead && tid == 0) ahead[q] = has_gt ? (red[0] + red[1]) + (red[2] + red[3]) : 0;
+    if (top_s && tid < 64) {
+        float ps = INFINITY;
+        int pi = -1;
+        bool done = false;
+        for (int o = 0; o < k; ++o) {
+            float bs = -INFINITY;
+            int bi = -1;
+            if (!done) {
+                for (int e = lane; e < 256 * KMAX; e += 64) {
+                    const int ei = xi[e];
+                    if (ei < 0) continue;
+                    const float es = xs[e];
+                    const bool after_prev = (o == 0) || rank_before(ps, pi, es, ei);
+                    if (after_prev && (bi < 0 || rank_before(es, ei, bs, bi))) { bs = es; bi = ei; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float os = __shfl_xor(bs, off);
+                    const int oi = __shfl_xor(bi, off);
+                    if (oi >= 0 && (bi < 0 || rank_before(os, oi, bs, bi))) { bs = os; bi = oi; }
+                }
+                if (bi < 0) done = true;
+            }
+            if (lane == 0) { top_s[(size_t)q * k + o] = bi >= 0 ? bs : -INFINITY; top_i[(size_t)q * k + o] = bi; }
+            ps = bs;
+            pi = bi;
+        }
+    }
+}
+
+}  // namespace kemr
+
+using namespace kemr;
+
+extern "C" int kemr_rank_dense(const float* scores_dev, int nq, int ng, int64_t ld, const int32_t* gt_idx_dev,
+                               int32_t* ahead_dev, int k, float* top_scores_dev, int32_t* top_idx_dev, void* stream) {
+    if (nq == 0) return KEMR_OK;
+    if (!scores_dev || nq < 0 || ng <= 0 || ld < ng) KEMR_FAIL(KEMR_ERR_INVALID, "rank_dense: bad argument");
+    if ((top_scores_dev != nullptr) != (top_idx_dev != nullptr)) KEMR_FAIL(KEMR_ERR_INVALID, "rank_dense: top_scores/top_idx together");
+    if (top_scores_dev && (k < 1 || k > 32)) KEMR_FAIL(KEMR_ERR_INVALID, "rank_dense: k=%d not in 1..32", k);
+    if ((gt_idx_dev != nullptr) != (ahead_dev != nullptr)) KEMR_FAIL(KEMR_ERR_INVALID, "rank_dense: gt_idx and ahead together");
+    hipStream_t s = (hipStream_t)stream;
+    if (!top_scores_dev || k <= 10) {
+        constexpr int KM = 10;
+        const size_t smem = 256 * KM * 8 + 16;
+        hipLaunchKernelGGL(rank_dense_kernel<KM>, dim3(nq), dim3(256), smem, s, scores_dev, (long long)ld, nq, ng, gt_idx_dev,
+                           ahead_dev, k, top_scores_dev, top_idx_dev);
+    } else {
+        constexpr int KM = 32;
+        const size_t smem = 256 * KM * 8 + 16;
+        auto kern = rank_dense_kernel<KM>;
+        KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, s, scores_dev, (long long)ld, nq, ng, gt_idx_dev, ahead_dev, k,
+                           top_scores_dev, top_idx_dev);
+    }
+    KEMR_CHECK_LAUNCH("rank_dense_kernel");
+    return KEMR_OK;
+}

@@ -1,0 +1,470 @@
+// Fused cosine-similarity + per-query top-k + rank-of-ground-truth; the Q x N score matrix never leaves the CU.
+//
+// Operands are bf16 "panels" [rows, kdim] (kemr_panel_build): fused T2I+T2T scoring concatenates the weighted
+// embedding sets along k (one contraction instead of two GEMMs + an N^2 axpy, reference metrics.py:145-148),
+// and terms == 3 appends the bf16 residuals so that hi*hi + lo*hi + hi*lo reproduces the fp32 products.
+//
+// sim_kernel: a 256-thread workgroup owns 128 queries and walks gallery tiles of 128 rows:
+//   1. K loop exactly like gemm.hip (LDS-DMA staging, chunk-XOR swizzle, v_mfma_f32_16x16x32_bf16; gallery
+//      fragment = A operand, query fragment = B operand) -> a 128 x 128 fp32 score tile in accumulators;
+//   2. the tile is dumped to LDS as S[query][candidate] (row stride 132 floats: conflict-free both ways);
+//   3. two scanner threads per query stream their 64 candidates: add the sparse SPARQL bonus (CSR cursor),
+//      count candidates ranked ahead of the ground truth, and keep a sorted top-KMAX list in registers
+//      (threshold test first, the insertion runs only on a hit).
+// Per (query, gallery chunk) partial lists go to the workspace and are merged by topk_merge_kernel, the same
+// kernel that merges per-GPU shards.  Order rule everywhere: higher score first, then lower candidate id.
+#include "common.h"
+
+namespace kemr {
+
+constexpr int SBK = 64;
+constexpr int ST = 128;          // tile edge (queries and candidates)
+constexpr int SLD = 132;         // LDS row stride of the score tile in floats
+
+__device__ __forceinline__ void glds16s(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------ panel build
+struct PanelArgs {
+    const float* parts[4];
+    const float* row_scale[4];
+    float part_scale[4];
+    int nparts, rows, rows_alloc, d, dpad, terms, side;
+    long long kdim;
+};
+
+__global__ __launch_bounds__(256) void panel_build_kernel(const PanelArgs a, bf16_t* __restrict__ out, long long total) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int half = a.dpad >> 1;
+    const int i = (int)(gid % half) * 2;
+    const long long t = gid / half;
+    const int p = (int)(t % a.nparts);
+    const long long row = t / a.nparts;
+    float v[2] = {0.f, 0.f};
+    if (row < a.rows) {
+        float sc = a.part_scale[p];
+        if (a.row_scale[p]) sc *= a.row_scale[p][row];
+        const float* src = a.parts[p] + (size_t)row * a.d;
+        if (i < a.d) v[0] = src[i] * sc;
+        if (i + 1 < a.d) v[1] = src[i + 1] * sc;
+    }
+    const bf16_t h0 = f32_to_bf16(v[0]), h1 = f32_to_bf16(v[1]);
+    const uint32_t hi = (uint32_t)h0 | ((uint32_t)h1 << 16);
+    bf16_t* dst = out + (size_t)row * a.kdim + (size_t)p * a.terms * a.dpad + i;
+    if (a.terms == 1) {
+        *(uint32_t*)dst = hi;
+    } else {
+        const uint32_t lo = pack_bf16x2(v[0] - bf16_to_f32(h0), v[1] - bf16_to_f32(h1));
+        // query panel [hi | lo | hi], gallery panel [hi | hi | lo]  ->  hi.hi + lo.hi + hi.lo
+        *(uint32_t*)dst = hi;
+        *(uint32_t*)(dst + a.dpad) = a.side == KEMR_SIDE_QUERY ? lo : hi;
+        *(uint32_t*)(dst + 2 * a.dpad) = a.side == KEMR_SIDE_QUERY ? hi : lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fused sim + top-k
+struct SimParams {
+    const bf16_t* Q;
+    const bf16_t* G;
+    int nq, ng, kdim;
+    long long goff;
+    int k;
+    float* part_scores;      // [nq, nchunks, k]
+    int32_t* part_idx;
+    const int32_t* gt_idx;
+    const float* gt_score;
+    int32_t* ahead;
+    const int32_t* brow;
+    const int32_t* bcol;
+    const float* bval;
+    float* dense;
+    long long ld_dense;
+    int nchunks, tiles_per_chunk, g_tiles;
+};
+
+template <int KMAX>
+__device__ __forceinline__ void topk_insert(float (&s)[KMAX], int (&id)[KMAX], float v, int idx) {
+#pragma unroll
+    for (int i = KMAX - 1; i > 0; --i) {
+        const bool shift = v > s[i - 1];
+        const bool here = !shift && v > s[i];
+        s[i] = shift ? s[i - 1] : (here ? v : s[i]);
+        id[i] = shift ? id[i - 1] : (here ? idx : id[i]);
+    }
+    if (v > s[0]) { s[0] = v; id[0] = idx; }
+}
+
+__device__ __forceinline__ bool ranks_before(float sa, int ia, float sb, int ib) {
+    return sa > sb || (sa == sb && ia < ib);
+}
+
+template <int KMAX, bool DENSE>
+__global__ __launch_bounds__(256) void sim_kernel(const SimParams p) {
+    constexpr int TILE_BYTES = ST * SBK * 2;             // 16 KiB per operand tile
+    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sS = (float*)(smem + 2 * STAGE_BYTES);        // [128][132] fp32 score tile (also the list exchange area)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wid >> 1, wcn = wid & 1;              // wave's query half / candidate half
+    const int qt = blockIdx.x / p.nchunks, chunk = blockIdx.x % p.nchunks;
+    const int tile_begin = chunk * p.tiles_per_chunk;
+    const int tile_end = min(tile_begin + p.tiles_per_chunk, p.g_tiles);
+
+    const int srow = lane >> 3, schunk = lane & 7;
+    const bf16_t* gQ = p.Q + (size_t)qt * ST * p.kdim;
+    const int lrow = lane & 15, lq = lane >> 4;
+    const int swz = lrow >> 1;
+    const int nt = p.kdim / SBK;
+
+    // scanner state: thread (q_local, half) owns candidates [half*64, half*64+64) of every tile for one query
+    const int q_local = tid & 127, half = tid >> 7;
+    const int qrow = qt * ST + q_local;
+    const bool q_valid = qrow < p.nq;
+    float ls[KMAX];
+    int li[KMAX];
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) { ls[i] = -INFINITY; li[i] = -1; }
+    int gt = -1, cnt = 0;
+    float sgt = 0.f;
+    int bcur = 0, bend = 0, next_col = INT_MAX;
+    if (!DENSE && q_valid) {
+        if (p.gt_idx) { gt = p.gt_idx[qrow]; sgt = p.gt_score[qrow]; }
+        if (p.brow) {
+            bcur = p.brow[qrow]; bend = p.brow[qrow + 1];
+            if (bcur < bend) next_col = p.bcol[bcur];
+        }
+    }
+
+    for (int gtile = tile_begin; gtile < tile_end; ++gtile) {
+        const bf16_t* gG = p.G + (size_t)gtile * ST * p.kdim;
+        auto stage = [&](int buf, int kt) {
+            char* sA = smem + buf * STAGE_BYTES;         // gallery tile
+            char* sB = sA + TILE_BYTES;                  // query tile
+            const int k0 = kt * SBK;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int piece = wid * 4 + j;
+                const int r = piece * 8 + srow;
+                const int c = schunk ^ ((r >> 1) & 7);
+                glds16s(gG + (size_t)r * p.kdim + k0 + c * 8, sA + piece * 1024);
+                glds16s(gQ + (size_t)r * p.kdim + k0 + c * 8, sB + piece * 1024);
+            }
+        };
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) acc[ci][qi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nt; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
+            const char* sA = smem + cur * STAGE_BYTES + (wcn * 64 + lrow) * 128;
+            const char* sB = smem + cur * STAGE_BYTES + TILE_BYTES + (wq * 64 + lrow) * 128;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int coff = ((kk * 4 + lq) ^ swz) << 4;
+                bf16x8 gf[4], qf[4];
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) gf[ci] = *(const bf16x8*)(sA + ci * 16 * 128 + coff);
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) qf[qi] = *(const bf16x8*)(sB + qi * 16 * 128 + coff);
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                    for (int qi = 0; qi < 4; ++qi)
+                        acc[ci][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ci], qf[qi], acc[ci][qi], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        // acc[ci][qi][r] = S[query wq*64 + qi*16 + lrow][candidate wcn*64 + ci*16 + lq*4 + r]
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                const f32x4 v = acc[ci][qi];
+                *(float4*)(sS + (wq * 64 + qi * 16 + lrow) * SLD + wcn * 64 + ci * 16 + lq * 4) =
+                    make_float4(v[0], v[1], v[2], v[3]);
+            }
+        __syncthreads();
+
+        const int cbase = gtile * ST;
+        if constexpr (DENSE) {
+            for (int r = wid * 32; r < wid * 32 + 32; ++r) {
+                const int qr = qt * ST + r;
+                const int c = cbase + lane * 2;
+                if (qr < p.nq) {
+                    const float2 v = *(const float2*)(sS + r * SLD + lane * 2);
+                    float* dst = p.dense + (size_t)qr * p.ld_dense + c;
+                    if (c < p.ng) dst[0] = v.x;
+                    if (c + 1 < p.ng) dst[1] = v.y;
+                }
+            }
+        } else if (q_valid) {
+            const float* rowp = sS + q_local * SLD + half * 64;
+#pragma unroll 4
+            for (int j4 = 0; j4 < 16; ++j4) {
+                const float4 v4 = *(const float4*)(rowp + j4 * 4);
+                const float ve[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int lid = cbase + half * 64 + j4 * 4 + e;
+                    if (lid >= p.ng) continue;
+                    const long long g64 = p.goff + lid;
+                    const int gid = (int)g64;
+                    float sc = ve[e];
+                    if (gid >= next_col) {                    // rare: this candidate may carry a SPARQL bonus
+                        while (bcur < bend && p.bcol[bcur] < gid) ++bcur;
+                        while (bcur < bend && p.bcol[bcur] == gid) { sc += p.bval[bcur]; ++bcur; }
+                        next_col = bcur < bend ? p.bcol[bcur] : INT_MAX;
+                    }
+                    if (gid != gt) cnt += ranks_before(sc, gid, sgt, gt) ? 1 : 0;
+                    if (sc > ls[KMAX - 1]) topk_insert<KMAX>(ls, li, sc, gid);
+                }
+            }
+        }
+        // no barrier needed here: the next write to sS happens after the barriers of the next K loop
+    }
+
+    if constexpr (!DENSE) {
+        __syncthreads();
+        float* xs = sS;                                   // [128][2][KMAX] scores
+        int* xi = (int*)(sS + ST * 2 * KMAX);             // [128][2][KMAX] ids
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+            xs[(q_local * 2 + half) * KMAX + i] = ls[i];
+            xi[(q_local * 2 + half) * KMAX + i] = li[i];
+        }
+        __syncthreads();
+        if (q_valid) {
+            if (p.ahead && gt >= 0 && cnt) atomicAdd(p.ahead + qrow, cnt);
+            if (half == 0 && p.part_scores) {
+                const float* as = xs + (q_local * 2) * KMAX;
+                const float* bs = as + KMAX;
+                const int* ai = xi + (q_local * 2) * KMAX;
+                const int* bi = ai + KMAX;
+                int ia = 0, ib = 0;
+                float* os = p.part_scores + ((size_t)qrow * p.nchunks + chunk) * p.k;
+                int32_t* oi = p.part_idx + ((size_t)qrow * p.nchunks + chunk) * p.k;
+                for (int o = 0; o < p.k; ++o) {
+                    const bool ta = ia < KMAX && ai[ia] >= 0, tb = ib < KMAX && bi[ib] >= 0;
+                    float so = -INFINITY;
+                    int io = -1;
+                    if (ta && (!tb || ranks_before(as[ia], ai[ia], bs[ib], bi[ib]))) { so = as[ia]; io = ai[ia]; ++ia; }
+                    else if (tb) { so = bs[ib]; io = bi[ib]; ++ib; }
+                    os[o] = so;
+                    oi[o] = io;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ list merge
+// one wave per query; k rounds of "best element strictly after the previous pick" over nlists*k entries
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ in_s, const int32_t* __restrict__ in_i,
+                                                         int nq, int total, int k, float* __restrict__ out_s,
+                                                         int32_t* __restrict__ out_i) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const float* s = in_s + (size_t)q * total;
+    const int32_t* ix = in_i + (size_t)q * total;
+    float ps = INFINITY;
+    int pi = -1;
+    for (int o = 0; o < k; ++o) {
+        float bs = -INFINITY;
+        int bi = -1;
+        for (int e = lane; e < total; e += 64) {
+            const float es = s[e];
+            const int ei = ix[e];
+            if (ei < 0) continue;
+            const bool after_prev = (o == 0) || ranks_before(ps, pi, es, ei);
+            if (after_prev && (bi < 0 || ranks_before(es, ei, bs, bi))) { bs = es; bi = ei; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float os = __shfl_xor(bs, off);
+            const int oi = __shfl_xor(bi, off);
+            if (oi >= 0 && (bi < 0 || ranks_before(os, oi, bs, bi))) { bs = os; bi = oi; }
+        }
+        if (lane == 0) { out_s[(size_t)q * k + o] = bi >= 0 ? bs : -INFINITY; out_i[(size_t)q * k + o] = bi; }
+        if (bi < 0) {                                     // exhausted: pad the rest
+            for (int r = o + 1 + lane; r < k; r += 64) { out_s[(size_t)q * k + r] = -INFINITY; out_i[(size_t)q * k + r] = -1; }
+            break;
+        }
+        ps = bs;
+        pi = bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pair scores
+// 16 (query row, gallery row) pairs per wave; same operand roles and k order as sim_kernel, diagonal extracted
+__global__ __launch_bounds__(64) void pair_scores_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ G,
+                                                         int kdim, const int32_t* __restrict__ qrows,
+                                                         const int32_t* __restrict__ grows, int npairs,
+                                                         float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, lrow = lane & 15, lq = lane >> 4;
+    const int pair = blockIdx.x * 16 + lrow;
+    const int pc = pair < npairs ? pair : npairs - 1;
+    const bf16_t* qp = Q + (size_t)qrows[pc] * kdim + lq * 8;
+    const bf16_t* gp = G + (size_t)grows[pc] * kdim + lq * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < kdim; k0 += 32) {
+        const bf16x8 gf = *(const bf16x8*)(gp + k0);
+        const bf16x8 qf = *(const bf16x8*)(qp + k0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, qf, acc, 0, 0, 0);
+    }
+    // D[row = candidate i][col = query j]; the pair's own score is D[i][i]: lane (lrow = i, lq = i >> 2), reg i & 3
+    if (lq == (lrow >> 2) && pair < npairs) {
+        const int r = lrow & 3;
+        out[pair] = r == 0 ? acc[0] : (r == 1 ? acc[1] : (r == 2 ? acc[2] : acc[3]));
+    }
+}
+
+}  // namespace kemr
+
+// ================================================================================================ C ABI
+using namespace kemr;
+
+extern "C" int64_t kemr_panel_kdim(int d, int nparts, int terms) {
+    if (d <= 0 || nparts <= 0 || (terms != 1 && terms != 3)) return -1;
+    return (int64_t)nparts * terms * round_up(d, 64);
+}
+
+extern "C" int kemr_panel_build(const float* const* parts_dev, const float* part_scale, const float* const* row_scale_dev,
+                                int nparts, int rows, int d, int terms, int side, void* panel_dev, void* stream) {
+    if (!parts_dev || !panel_dev) KEMR_FAIL(KEMR_ERR_INVALID, "panel_build: null pointer");
+    if (nparts < 1 || nparts > 4) KEMR_FAIL(KEMR_ERR_INVALID, "panel_build: nparts %d not in 1..4", nparts);
+    if (terms != 1 && terms != 3) KEMR_FAIL(KEMR_ERR_INVALID, "panel_build: terms must be 1 or 3");
+    if (rows < 0 || d <= 0) KEMR_FAIL(KEMR_ERR_INVALID, "panel_build: bad shape rows=%d d=%d", rows, d);
+    if (side != KEMR_SIDE_QUERY && side != KEMR_SIDE_GALLERY) KEMR_FAIL(KEMR_ERR_INVALID, "panel_build: bad side");
+    PanelArgs a;
+    for (int p = 0; p < 4; ++p) {
+        a.parts[p] = p < nparts ? parts_dev[p] : nullptr;
+        a.row_scale[p] = (p < nparts && row_scale_dev) ? row_scale_dev[p] : nullptr;
+        a.part_scale[p] = (p < nparts && part_scale) ? part_scale[p] : 1.0f;
+        if (p < nparts && !a.parts[p]) KEMR_FAIL(KEMR_ERR_INVALID, "panel_build: part %d is null", p);
+    }
+    a.nparts = nparts; a.rows = rows; a.rows_alloc = (int)round_up(rows, 128); a.d = d; a.dpad = (int)round_up(d, 64);
+    a.terms = terms; a.side = side; a.kdim = kemr_panel_kdim(d, nparts, terms);
+    const long long total = (long long)a.rows_alloc * nparts * (a.dpad / 2);
+    if (total == 0) return KEMR_OK;
+    hipLaunchKernelGGL(panel_build_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       (bf16_t*)panel_dev, total);
+    KEMR_CHECK_LAUNCH("panel_build_kernel");
+    return KEMR_OK;
+}
+
+static int sim_chunks(int nq, int ng, int* tiles_per_chunk) {
+    const int q_tiles = (nq + ST - 1) / ST, g_tiles = (ng + ST - 1) / ST;
+    int want = (768 + q_tiles - 1) / q_tiles;           // aim for >= 3 workgroups per CU
+    if (want > g_tiles) want = g_tiles;
+    if (want < 1) want = 1;
+    const int tpc = (g_tiles + want - 1) / want;
+    *tiles_per_chunk = tpc;
+    return (g_tiles + tpc - 1) / tpc;
+}
+
+extern "C" size_t kemr_sim_workspace_bytes(int nq, int ng, int k) {
+    if (nq <= 0 || ng <= 0 || k <= 0) return 0;
+    int tpc;
+    const int nchunks = sim_chunks(nq, ng, &tpc);
+    return (size_t)round_up((int64_t)nq * nchunks * k * 8, 256);
+}
+
+template <int KMAX, bool DENSE>
+static int launch_sim(const SimParams& p, hipStream_t stream) {
+    constexpr int smem = 2 * 2 * ST * SBK * 2 + ST * SLD * 4;
+    auto kern = sim_kernel<KMAX, DENSE>;
+    KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    const int q_tiles = (p.nq + ST - 1) / ST;
+    ProfScope prof(PROF_SIM, stream);
+    hipLaunchKernelGGL(kern, dim3(q_tiles * p.nchunks), dim3(256), smem, stream, p);
+    KEMR_CHECK_LAUNCH("sim_kernel");
+    return KEMR_OK;
+}
+
+static int check_panels(const void* q, int nq, const void* g, int ng, int64_t kdim) {
+    if (!q || !g) KEMR_FAIL(KEMR_ERR_INVALID, "sim: null panel");
+    if (nq <= 0 || ng <= 0) KEMR_FAIL(KEMR_ERR_INVALID, "sim: empty operand (nq=%d ng=%d)", nq, ng);
+    if (kdim <= 0 || kdim % 64 != 0 || kdim > (1 << 20)) KEMR_FAIL(KEMR_ERR_INVALID, "sim: kdim %lld must be a positive multiple of 64", (long long)kdim);
+    return KEMR_OK;
+}
+
+extern "C" int kemr_sim_topk(const void* q_panel_dev, int nq, const void* g_panel_dev, int ng, int64_t kdim,
+                             int64_t gallery_offset, int k, float* top_scores_dev, int32_t* top_idx_dev,
+                             const int32_t* gt_idx_dev, const float* gt_score_dev, int32_t* ahead_dev,
+                             const int32_t* bonus_rowptr_dev, const int32_t* bonus_col_dev, const float* bonus_val_dev,
+                             void* workspace_dev, size_t workspace_bytes, void* stream) {
+    KEMR_TRY(check_panels(q_panel_dev, nq, g_panel_dev, ng, kdim));
+    if (k < 1 || k > 32) KEMR_FAIL(KEMR_ERR_INVALID, "sim_topk: k=%d not in 1..32", k);
+    if (!top_scores_dev || !top_idx_dev) KEMR_FAIL(KEMR_ERR_INVALID, "sim_topk: null output");
+    if ((gt_idx_dev != nullptr) != (gt_score_dev != nullptr) || (gt_idx_dev != nullptr) != (ahead_dev != nullptr))
+        KEMR_FAIL(KEMR_ERR_INVALID, "sim_topk: gt_idx, gt_score and ahead must be given together");
+    if ((bonus_rowptr_dev != nullptr) != (bonus_col_dev != nullptr) || (bonus_rowptr_dev != nullptr) != (bonus_val_dev != nullptr))
+        KEMR_FAIL(KEMR_ERR_INVALID, "sim_topk: bonus CSR arrays must be given together");
+    if (gallery_offset < 0 || gallery_offset + ng > 0x7fffffffLL) KEMR_FAIL(KEMR_ERR_INVALID, "sim_topk: candidate ids exceed int32");
+    const size_t need = kemr_sim_workspace_bytes(nq, ng, k);
+    if (!workspace_dev || workspace_bytes < need) KEMR_FAIL(KEMR_ERR_WORKSPACE, "sim_topk: workspace %zu < %zu bytes", workspace_bytes, need);
+    SimParams p{};
+    p.Q = (const bf16_t*)q_panel_dev; p.G = (const bf16_t*)g_panel_dev; p.nq = nq; p.ng = ng; p.kdim = (int)kdim;
+    p.goff = gallery_offset; p.k = k;
+    p.nchunks = sim_chunks(nq, ng, &p.tiles_per_chunk);
+    p.g_tiles = (ng + ST - 1) / ST;
+    p.part_scores = (float*)workspace_dev;
+    p.part_idx = (int32_t*)((char*)workspace_dev + (size_t)nq * p.nchunks * k * 4);
+    p.gt_idx = gt_idx_dev; p.gt_score = gt_score_dev; p.ahead = ahead_dev;
+    p.brow = bonus_rowptr_dev; p.bcol = bonus_col_dev; p.bval = bonus_val_dev;
+    hipStream_t s = (hipStream_t)stream;
+    if (k <= 10) KEMR_TRY((launch_sim<10, false>(p, s)));
+    else KEMR_TRY((launch_sim<32, false>(p, s)));
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, p.part_scores, p.part_idx, nq, p.nchunks * k, k,
+                       top_scores_dev, top_idx_dev);
+    KEMR_CHECK_LAUNCH("topk_merge_kernel");
+    return KEMR_OK;
+}
+
+extern "C" int kemr_scores_dense(const void* q_panel_dev, int nq, const void* g_panel_dev, int ng, int64_t kdim,
+                                 float* out_dev, int64_t ld_out, void* stream) {
+    KEMR_TRY(check_panels(q_panel_dev, nq, g_panel_dev, ng, kdim));
+    if (!out_dev || ld_out < ng) KEMR_FAIL(KEMR_ERR_INVALID, "scores_dense: bad output (ld=%lld)", (long long)ld_out);
+    SimParams p{};
+    p.Q = (const bf16_t*)q_panel_dev; p.G = (const bf16_t*)g_panel_dev; p.nq = nq; p.ng = ng; p.kdim = (int)kdim;
+    p.k = 1; p.dense = out_dev; p.ld_dense = ld_out;
+    p.nchunks = sim_chunks(nq, ng, &p.tiles_per_chunk);
+    p.g_tiles = (ng + ST - 1) / ST;
+    return launch_sim<10, true>(p, (hipStream_t)stream);
+}
+
+extern "C" int kemr_pair_scores(const void* q_panel_dev, const void* g_panel_dev, int64_t kdim, const int32_t* q_rows_dev,
+                                const int32_t* g_rows_dev, int npairs, float* out_dev, void* stream) {
+    if (npairs == 0) return KEMR_OK;
+    if (!q_panel_dev || !g_panel_dev || !q_rows_dev || !g_rows_dev || !out_dev || npairs < 0)
+        KEMR_FAIL(KEMR_ERR_INVALID, "pair_scores: bad argument");
+    if (kdim <= 0 || kdim % 64 != 0) KEMR_FAIL(KEMR_ERR_INVALID, "pair_scores: kdim must be a positive multiple of 64");
+    hipLaunchKernelGGL(pair_scores_kernel, dim3((npairs + 15) / 16), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)q_panel_dev,
+                       (const bf16_t*)g_panel_dev, (int)kdim, q_rows_dev, g_rows_dev, npairs, out_dev);
+    KEMR_CHECK_LAUNCH("pair_scores_kernel");
+    return KEMR_OK;
+}
+
+extern "C" int kemr_topk_merge(const float* in_scores_dev, const int32_t* in_idx_dev, int nq, int nlists, int k,
+                               float* out_scores_dev, int32_t* out_idx_dev, void* stream) {
+    if (nq == 0) return KEMR_OK;
+    if (!in_scores_dev || !in_idx_dev || !out_scores_dev || !out_idx_dev || nq < 0 || nlists < 1 || k < 1)
+        KEMR_FAIL(KEMR_ERR_INVALID, "topk_merge: bad argument");
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((nq + 3) / 4), dim3(256), 0, (hipStream_t)stream, in_scores_dev, in_idx_dev, nq,
+                       nlists * k, k, out_scores_dev, out_idx_dev);
+    KEMR_CHECK_LAUNCH("topk_merge_kernel");
+    return KEMR_OK;
+}

@@ -1,0 +1,321 @@
+"""Host-side driver of libkemr.so: model handle, encoders and the fused similarity / top-k / rank ops.
+
+PyTorch is plumbing here (device memory, streams): every tensor that crosses into the library is passed as
+``tensor.data_ptr()`` and all arithmetic of the hot path runs in the HIP kernels behind the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Mapping, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from .config import ClipArch
+
+# rows per encoder launch: picked so that batch * tokens fills whole 128/256-row GEMM tiles and the
+# workspace (14 * width bytes per token) stays small; larger user batches are processed in slices.
+MAX_IMAGE_BATCH = 255
+MAX_TEXT_BATCH = 851
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_cuda(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must live on the GPU (got device {t.device}); this path has no CPU fallback")
+
+
+class ClipEngine:
+    """One packed CLIP model (both towers) in HBM."""
+
+    def __init__(self, arch: ClipArch, device: torch.device | str = "cuda:0"):
+        self.arch = arch
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("ClipEngine needs a GPU device; the HIP path has no CPU fallback")
+        self._L = _lib.lib()
+        cfg = _lib.KemrCfg(**arch.as_dict())
+        h = C.c_void_p()
+        _lib.check(self._L.kemr_model_create(C.byref(cfg), C.byref(h)), "model_create")
+        self._h = h
+        self._ws: Dict[int, torch.Tensor] = {}
+        self.ready = False
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._L.kemr_model_destroy(h)
+            except Exception:
+                pass
+
+    # ------------------------------------------------------------------ weights
+    def tensor_names(self) -> Sequence[str]:
+        n = self._L.kemr_model_num_tensors(self._h)
+        return [self._L.kemr_model_tensor_name(self._h, i).decode() for i in range(n)]
+
+    def load_state_dict(self, sd: Mapping[str, torch.Tensor]) -> None:
+        """Strict load of an OpenAI-CLIP style state dict (any float dtype, any device) + pack to HBM."""
+        for name, t in sd.items():
+            if not torch.is_tensor(t):
+                continue
+            host = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+            shape = (C.c_int64 * max(host.dim(), 1))(*host.shape)
+            _lib.check(self._L.kemr_model_load_tensor(self._h, name.encode(), C.c_void_p(host.data_ptr()), _lib.KEMR_F32,
+                                                      shape, host.dim()), f"load_tensor({name})")
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.kemr_model_finalize(self._h, _lib.PREC_BF16), "model_finalize")
+        self.ready = True
+
+    # ------------------------------------------------------------------ encoders
+    def _workspace(self, tower: int, batch: int) -> torch.Tensor:
+        need = int(self._L.kemr_workspace_bytes(self._h, tower, batch))
+        ws = self._ws.get(tower)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws[tower] = ws
+        return ws
+
+    def _encode(self, fn, tower: int, x: torch.Tensor, max_batch: int, normalize: bool) -> torch.Tensor:
+        if not self.ready:
+            raise RuntimeError("ClipEngine: load_state_dict() must be called before encoding")
+        n = x.shape[0]
+        out = torch.empty((n, self.arch.embed_dim), dtype=torch.float32, device=self.device)
+        if n == 0:
+            return out
+        with torch.cuda.device(self.device):
+            stream = _stream_ptr(self.device)
+            ws = self._workspace(tower, min(n, max_batch))
+            for s in range(0, n, max_batch):
+                xb = x[s:s + max_batch]
+                _lib.check(fn(self._h, C.c_void_p(xb.data_ptr()), xb.shape[0], C.c_void_p(out[s:].data_ptr()),
+                              1 if normalize else 0, C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(stream)),
+                           "encode")
+        return out
+
+    def encode_image(self, pixels: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+        a = self.arch
+        _require_cuda(pixels, "pixels")
+        if pixels.dim() != 4 or tuple(pixels.shape[1:]) != (3, a.image_size, a.image_size):
+            raise RuntimeError(f"encode_image expects [B,3,{a.image_size},{a.image_size}], got {tuple(pixels.shape)}")
+        pixels = pixels.to(dtype=torch.float32).contiguous()
+        return self._encode(self._L.kemr_encode_image, _lib.TOWER_VISION, pixels, MAX_IMAGE_BATCH, normalize)
+
+    def encode_text(self, ids: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+        a = self.arch
+        _require_cuda(ids, "token ids")
+        if ids.dim() != 2 or ids.shape[1] != a.ctx:
+            raise RuntimeError(f"encode_text expects [B,{a.ctx}] token ids, got {tuple(ids.shape)}")
+        ids = ids.to(dtype=torch.int32).contiguous()
+        return self._encode(self._L.kemr_encode_text, _lib.TOWER_TEXT, ids, MAX_TEXT_BATCH, normalize)
+
+
+# ====================================================================== similarity / ranking ops
+
+def rows_alloc(rows: int) -> int:
+    return (rows + 127) // 128 * 128
+
+
+class Panel:
+    """bf16 operand of the fused similarity kernels: [rows (padded to 128), kdim]."""
+
+    def __init__(self, data: torch.Tensor, rows: int, kdim: int, terms: int, side: int):
+        self.data, self.rows, self.kdim, self.terms, self.side = data, rows, kdim, terms, side
+
+    @property
+    def device(self):
+        return self.data.device
+
+
+def build_panel(parts: Sequence[torch.Tensor], side: int, terms: int = 3,
+                part_scale: Optional[Sequence[float]] = None,
+                row_scale: Optional[Sequence[Optional[torch.Tensor]]] = None) -> Panel:
+    """Concatenate weighted embedding sets along k and split to bf16 (see include/kemr.h)."""
+    L = _lib.lib()
+    parts = [p.to(torch.float32).contiguous() for p in parts]
+    for p in parts:
+        _require_cuda(p, "embeddings")
+    rows, d = parts[0].shape
+    if any(tuple(p.shape) != (rows, d) for p in parts):
+        raise RuntimeError("build_panel: all parts must share one [rows, d] shape")
+    n = len(parts)
+    kdim = int(L.kemr_panel_kdim(d, n, terms))
+    if kdim <= 0:
+        raise RuntimeError(f"build_panel: unsupported d={d} nparts={n} terms={terms}")
+    dev = parts[0].device
+    out = torch.empty((rows_alloc(max(rows, 1)), kdim), dtype=torch.bfloat16, device=dev)
+    pp = (C.c_void_p * n)(*[p.data_ptr() for p in parts])
+    ps = (C.c_float * n)(*(list(part_scale) if part_scale is not None else [1.0] * n))
+    keep = []
+    if row_scale is not None:
+        rs = []
+        for r in row_scale:
+            if r is None:
+                rs.append(None)
+            else:
+                r = r.to(device=dev, dtype=torch.float32).contiguous().view(-1)
+                if r.numel() != rows:
+                    raise RuntimeError("build_panel: row_scale must have one entry per row")
+                keep.append(r)
+                rs.append(r.data_ptr())
+        prs = (C.c_void_p * n)(*rs)
+    else:
+        prs = None
+    with torch.cuda.device(dev):
+        _lib.check(L.kemr_panel_build(pp, ps, prs, n, rows, d, terms, side, C.c_void_p(out.data_ptr()),
+                                      C.c_void_p(_stream_ptr(dev))), "panel_build")
+    return Panel(out, rows, kdim, terms, side)
+
+
+def _opt_ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def pair_scores(qp: Panel, gp: Panel, q_rows: torch.Tensor, g_rows: torch.Tensor) -> torch.Tensor:
+    L = _lib.lib()
+    q_rows = q_rows.to(device=qp.device, dtype=torch.int32).contiguous()
+    g_rows = g_rows.to(device=qp.device, dtype=torch.int32).contiguous()
+    n = q_rows.numel()
+    out = torch.empty(n, dtype=torch.float32, device=qp.device)
+    if n:
+        with torch.cuda.device(qp.device):
+            _lib.check(L.kemr_pair_scores(C.c_void_p(qp.data.data_ptr()), C.c_void_p(gp.data.data_ptr()), qp.kdim,
+                                          C.c_void_p(q_rows.data_ptr()), C.c_void_p(g_rows.data_ptr()), n,
+                                          C.c_void_p(out.data_ptr()), C.c_void_p(_stream_ptr(qp.device))), "pair_scores")
+    return out
+
+
+def sim_topk(qp: Panel, gp: Panel, k: int, gallery_offset: int = 0,
+             gt_idx: Optional[torch.Tensor] = None, gt_score: Optional[torch.Tensor] = None,
+             ahead: Optional[torch.Tensor] = None,
+             bonus: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
+             ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Fused scores + top-k (+ `ahead` counts when a ground truth is given). Returns (scores [nq,k], ids [nq,k])."""
+    L = _lib.lib()
+    if qp.kdim != gp.kdim:
+        raise RuntimeError(f"sim_topk: panel kdim mismatch ({qp.kdim} vs {gp.kdim})")
+    dev = qp.device
+    nq, ng = qp.rows, gp.rows
+    top_s = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    top_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    if nq == 0:
+        return top_s, top_i
+    if ng == 0:
+        return top_s.fill_(float("-inf")), top_i.fill_(-1)
+    ws = torch.empty(int(L.kemr_sim_workspace_bytes(nq, ng, k)), dtype=torch.uint8, device=dev)
+    if gt_idx is not None:
+        if gt_score is None or ahead is None:
+            raise RuntimeError("sim_topk: gt_idx needs gt_score and ahead")
+        gt_idx = gt_idx.to(device=dev, dtype=torch.int32).contiguous()
+        gt_score = gt_score.to(device=dev, dtype=torch.float32).contiguous()
+        if ahead.dtype != torch.int32 or not ahead.is_contiguous() or ahead.device != dev:
+            raise RuntimeError("sim_topk: ahead must be a contiguous int32 tensor on the panel's device")
+    b_ptr = b_col = b_val = None
+    if bonus is not None:
+        b_ptr, b_col, b_val = (bonus[0].to(device=dev, dtype=torch.int32).contiguous(),
+                               bonus[1].to(device=dev, dtype=torch.int32).contiguous(),
+                               bonus[2].to(device=dev, dtype=torch.float32).contiguous())
+        if b_ptr.numel() != nq + 1:
+            raise RuntimeError("sim_topk: bonus row pointer must have nq + 1 entries")
+    with torch.cuda.device(dev):
+        _lib.check(L.kemr_sim_topk(C.c_void_p(qp.data.data_ptr()), nq, C.c_void_p(gp.data.data_ptr()), ng, qp.kdim,
+                                   gallery_offset, k, C.c_void_p(top_s.data_ptr()), C.c_void_p(top_i.data_ptr()),
+                                   _opt_ptr(gt_idx), _opt_ptr(gt_score), _opt_ptr(ahead),
+                                   _opt_ptr(b_ptr), _opt_ptr(b_col), _opt_ptr(b_val),
+                                   C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(_stream_ptr(dev))), "sim_topk")
+    return top_s, top_i
+
+
+def topk_merge(scores: torch.Tensor, idx: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[nq, nlists, k] candidate lists -> [nq, k] (score desc, id asc)."""
+    L = _lib.lib()
+    _require_cuda(scores, "scores")
+    nq, nlists, kk = scores.shape
+    if kk != k or tuple(idx.shape) != tuple(scores.shape):
+        raise RuntimeError("topk_merge: expected scores/idx of shape [nq, nlists, k]")
+    scores = scores.to(torch.float32).contiguous()
+    idx = idx.to(torch.int32).contiguous()
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((nq, k), dtype=torch.int32, device=scores.device)
+    if nq:
+        with torch.cuda.device(scores.device):
+            _lib.check(L.kemr_topk_merge(C.c_void_p(scores.data_ptr()), C.c_void_p(idx.data_ptr()), nq, nlists, k,
+                                         C.c_void_p(out_s.data_ptr()), C.c_void_p(out_i.data_ptr()),
+                                         C.c_void_p(_stream_ptr(scores.device))), "topk_merge")
+    return out_s, out_i
+
+
+def scores_dense(qp: Panel, gp: Panel) -> torch.Tensor:
+    """Dense fp32 score matrix [nq, ng] (fusion heads that need every pair; debugging)."""
+    L = _lib.lib()
+    if qp.kdim != gp.kdim:
+        raise RuntimeError("scores_dense: panel kdim mismatch")
+    out = torch.empty((qp.rows, gp.rows), dtype=torch.float32, device=qp.device)
+    if qp.rows and gp.rows:
+        with torch.cuda.device(qp.device):
+            _lib.check(L.kemr_scores_dense(C.c_void_p(qp.data.data_ptr()), qp.rows, C.c_void_p(gp.data.data_ptr()), gp.rows,
+                                           qp.kdim, C.c_void_p(out.data_ptr()), gp.rows,
+                                           C.c_void_p(_stream_ptr(qp.device))), "scores_dense")
+    return out
+
+
+def rank_dense(scores: torch.Tensor, gt_idx: Optional[torch.Tensor] = None, k: int = 0
+               ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """Rank a materialised fp32 score matrix on the GPU: returns (ahead [nq] or None, top scores, top ids)."""
+    L = _lib.lib()
+    _require_cuda(scores, "score matrix")
+    scores = scores.to(torch.float32)
+    if scores.stride(-1) != 1:
+        scores = scores.contiguous()
+    nq, ng = scores.shape
+    dev = scores.device
+    ahead = gt = top_s = top_i = None
+    if gt_idx is not None:
+        gt = gt_idx.to(device=dev, dtype=torch.int32).contiguous()
+        ahead = torch.zeros(nq, dtype=torch.int32, device=dev)
+    if k > 0:
+        top_s = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        top_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    if nq and ng:
+        with torch.cuda.device(dev):
+            _lib.check(L.kemr_rank_dense(C.c_void_p(scores.data_ptr()), nq, ng, scores.stride(0), _opt_ptr(gt), _opt_ptr(ahead),
+                                         k, _opt_ptr(top_s), _opt_ptr(top_i), C.c_void_p(_stream_ptr(dev))), "rank_dense")
+    return ahead, top_s, top_i
+
+
+# ---------------------------------------------------------------------- per-kernel hooks used by tests
+def op_gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], m: int, epilogue: int,
+            c: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a: bf16 [m_alloc, k] (m_alloc multiple of 256), w: bf16 [n, k]; returns C (bf16 [m_alloc, n] or the fp32 residual)."""
+    L = _lib.lib()
+    n, k = w.shape
+    if c is None:
+        c = torch.zeros((a.shape[0], n), dtype=torch.bfloat16 if epilogue != _lib.EPI_BIAS_RESID_F32 else torch.float32,
+                        device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(L.kemr_op_gemm(C.c_void_p(a.data_ptr()), C.c_void_p(w.data_ptr()), _opt_ptr(bias), C.c_void_p(c.data_ptr()),
+                                  m, n, k, epilogue, C.c_void_p(_stream_ptr(a.device))), "op_gemm")
+    return c
+
+
+def op_layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_bf16: bool = True) -> torch.Tensor:
+    L = _lib.lib()
+    rows, width = x.shape
+    y = torch.empty((rows, width), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(L.kemr_op_layernorm(C.c_void_p(x.data_ptr()), C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()),
+                                       C.c_void_p(y.data_ptr()), rows, width, _lib.KEMR_BF16 if out_bf16 else _lib.KEMR_F32,
+                                       C.c_void_p(_stream_ptr(x.device))), "op_layernorm")
+    return y
+
+
+def op_attention(qkv: torch.Tensor, batch: int, t: int, width: int, causal: bool) -> torch.Tensor:
+    L = _lib.lib()
+    out = torch.empty((batch * t, width), dtype=torch.bfloat16, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        _lib.check(L.kemr_op_attention(C.c_void_p(qkv.data_ptr()), C.c_void_p(out.data_ptr()), batch, t, width,
+                                       1 if causal else 0, C.c_void_p(_stream_ptr(qkv.device))), "op_attention")
+    return out

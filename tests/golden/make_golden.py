@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors under tests/golden/.
+
+Runs ONLY in the build container: it imports the reference's own importable modules from
+/root/reference (``src.clip.eval.metrics``, ``src.clip.eval.fusion``, ``src.clip.model.fusion_model``)
+and a from-config ``transformers.CLIPModel`` (the class the reference calls in
+``src/clip/eval/evaluator_hf.py``), feeds them seeded synthetic inputs and stores inputs + outputs.
+Nothing here is needed (or present) on the GPU box; the tests read only the files it wrote.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+
+
+def ref_modules():
+    """Import the reference packages without shadowing this repo's own ``src`` package."""
+    saved = {k: v for k, v in sys.modules.items() if k == "src" or k.startswith("src.")}
+    for k in saved:
+        del sys.modules[k]
+    sys.path.insert(0, REF)
+    try:
+        import importlib
+        metrics = importlib.import_module("src.clip.eval.metrics")
+        fusion = importlib.import_module("src.clip.eval.fusion")
+        fusion_model = importlib.import_module("src.clip.model.fusion_model")
+        assert metrics.__file__.startswith(REF), metrics.__file__
+    finally:
+        sys.path.remove(REF)
+        for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    return metrics, fusion, fusion_model
+
+
+def quiet(fn, *a, **kw):
+    with redirect_stdout(io.StringIO()):
+        return fn(*a, **kw)
+
+
+def main():
+    from oracle import clip_ref, metrics_ref
+    metrics, fusion, fusion_model = ref_modules()
+
+    # ------------------------------------------------------------------ 1. metrics (SURVEY 8(c) recipe)
+    for n, d, tag in ((256, 768, "n256_d768"), (192, 128, "n192_d128")):
+        img, q, t = metrics_ref.planted_embeddings(n, d, seed=0)
+        S = q @ img.T
+        out = {
+            "image": img, "query": q, "target": t,
+            "all_keys": None, "all_vals": None,
+        }
+        allm = metrics.compute_all_retrieval_metrics(q, t, img)
+        final_55 = quiet(metrics.compute_retrieval_metrics_final, q, t, img, t2i_weight=0.5, t2t_weight=0.5)
+        final_19 = quiet(metrics.compute_retrieval_metrics_final, q, t, img, prefix="F", t2i_weight=0.1, t2t_weight=0.9)
+        train = metrics.compute_training_metrics(q, t, img)
+        fus = metrics.compute_retrieval_metrics_fusion(0.5 * (q @ img.T) + 0.5 * (q @ t.T), prefix="X")
+        ev = quiet(fusion.evaluate_retrieval, S)
+        order = np.argsort(-S, axis=1)
+        ranks = np.argmax(order == np.arange(n)[:, None], axis=1) + 1
+        del out["all_keys"], out["all_vals"]
+        np.savez_compressed(
+            os.path.join(HERE, f"metrics_{tag}.npz"), **out,
+            t2i_top10=order[:, :10].astype(np.int32), t2i_ranks=ranks.astype(np.int32),
+            metrics_json=np.frombuffer(json.dumps({
+                "all": allm, "final_0.5_0.5": final_55, "final_0.1_0.9_prefixF": final_19,
+                "training": train, "fusion_prefixX": fus, "evaluate_retrieval_t2i": ev,
+            }, sort_keys=True).encode(), dtype=np.uint8))
+        print(tag, {k: round(v, 4) for k, v in allm.items() if k.startswith("T2I")})
+
+    # ------------------------------------------------------------------ 2. SPARQL score fusion
+    rng = np.random.default_rng(7)
+    n = 48
+    S = rng.standard_normal((n, n)).astype(np.float32) * 0.1
+    uuids = [f"uuid-{i:04d}" for i in range(n)]
+    results = {}
+    for i in range(0, n, 2):
+        k = int(rng.integers(0, 9)) if i % 6 else 60
+        picks = rng.integers(0, n + 6, size=k)       # some ids fall outside the gallery
+        results[uuids[i]] = [
+            (f"http://example.org/artefact/uuid-{j:04d}" if (j % 3) else f"uuid-{j:04d}") for j in picks]
+    results[uuids[0]] = []                             # empty result set
+    fused = {
+        "weighted_a0.7": quiet(fusion.fuse_clip_and_text2sparql, S, results, uuids, uuids, "weighted",
+                               {"alpha": 0.7, "sparql_weight": 0.3}),
+        "weighted_a0.6_w0.6": quiet(fusion.weighted_fusion, S, results, uuids, uuids, 0.6, 0.6),
+        "additive_d0.5": quiet(fusion.fuse_clip_and_text2sparql, S, results, uuids, uuids, "additive", {"delta": 0.5}),
+        "adaptive_d0.5": quiet(fusion.fuse_clip_and_text2sparql, S, results, uuids, uuids, "adaptive", {"delta": 0.5}),
+    }
+    fmetrics = {k: quiet(fusion.evaluate_retrieval, v) for k, v in fused.items()}
+    np.savez_compressed(os.path.join(HERE, "sparql_fusion.npz"), S=S, **fused,
+                        meta_json=np.frombuffer(json.dumps({"uuids": uuids, "results": results,
+                                                            "metrics": fmetrics}).encode(), dtype=np.uint8))
+    print("sparql fusion", {k: round(v["MRR"], 3) for k, v in fmetrics.items()})
+
+    # ------------------------------------------------------------------ 3. learned fusion heads (eval mode)
+    D, Nq, M = 64, 12, 20
+    g = torch.Generator().manual_seed(11)
+    qe = torch.nn.functional.normalize(torch.randn(Nq, D, generator=g), dim=-1)
+    ie = torch.nn.functional.normalize(torch.randn(M, D, generator=g), dim=-1)
+    te = torch.nn.functional.normalize(torch.randn(M, D, generator=g), dim=-1)
+    heads = {"q": qe.numpy(), "img": ie.numpy(), "tgt": te.numpy()}
+
+    class _NoClip(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+    for ft in ("linear", "gated", "simple_gated", "simple_gated_with_bias", "bilinear", "cross_attention"):
+        torch.manual_seed(3)
+        fm = fusion_model.FusionModel(_NoClip(), fusion_type=ft, embed_dim=D).eval()
+        with torch.no_grad():
+            for p in fm.fusion_head.parameters():      # zero-initialised params would make the test vacuous
+                p.add_(torch.randn(p.shape, generator=g) * 0.2)
+            out = fm(qe, ie, te)
+        heads[f"{ft}__out"] = out.numpy()
+        for k, v in fm.fusion_head.state_dict().items():
+            heads[f"{ft}__sd__{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "fusion_heads.npz"), **heads)
+    print("heads ok")
+
+    # ------------------------------------------------------------------ 4. encoder cross-check (HF from-config)
+    from transformers import CLIPConfig, CLIPModel
+    for name in ("tiny", "tiny-long"):
+        arch = clip_ref.ARCHS[name]
+        sd = clip_ref.random_state_dict(arch, seed=0)
+        cfg = CLIPConfig(**clip_ref.hf_config_kwargs(arch))
+        cfg._attn_implementation = "eager"
+        m = CLIPModel(cfg).eval().float()
+        m.load_state_dict(clip_ref.to_hf_state_dict(sd, arch), strict=True)
+        gg = torch.Generator().manual_seed(1234)
+        px = torch.randn(4, 3, arch["image_size"], arch["image_size"], generator=gg)
+        ids = clip_ref.synthetic_ids(arch, 6)
+        with torch.no_grad():
+            hi = m.get_image_features(pixel_values=px)
+            hi = hi if torch.is_tensor(hi) else hi.pooler_output
+            ht = m.get_text_features(input_ids=ids.long())
+            ht = ht if torch.is_tensor(ht) else ht.pooler_output
+        chk = {k: float(v.double().abs().sum()) for k, v in sd.items()}
+        np.savez_compressed(os.path.join(HERE, f"clip_hf_{name}.npz"), pixels=px.numpy(), ids=ids.numpy(),
+                            image_features=hi.numpy(), text_features=ht.numpy(),
+                            weight_abs_sums=np.frombuffer(json.dumps(chk, sort_keys=True).encode(), dtype=np.uint8))
+        oi = clip_ref.encode_image(sd, arch, px)
+        ot = clip_ref.encode_text(sd, arch, ids)
+        print(name, "oracle vs HF:", float((oi - hi).abs().max()), float((ot - ht).abs().max()))
+
+    # ------------------------------------------------------------------ 5. RetrievalEngine linear fuse (retrieval.py:23-76 is
+    # not importable: it needs dotenv + network-bound constructors; the vector below restates its documented arithmetic on a
+    # hand-checkable case and is marked "restated", not "reference-generated")
+    clip_results = [{"uuid": f"u{i}", "score": s} for i, s in enumerate([0.91234, 0.5, 0.49996, 0.3, 0.12345, -0.2])]
+    sparql = ["u3", "u5", "zz"]
+    expect = sorted(({"uuid": it["uuid"], "score": round(0.8 * it["score"] + 0.2 * (it["uuid"] in sparql), 4)}
+                     for it in clip_results), key=lambda x: x["score"], reverse=True)
+    with open(os.path.join(HERE, "engine_fuse.json"), "w") as f:
+        json.dump({"origin": "restated from src/retrieval.py:23-76 (module not importable offline)",
+                   "clip_results": clip_results, "sparql_results": sparql, "alpha": 0.8, "beta": 0.2,
+                   "expected": expect}, f, indent=1)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

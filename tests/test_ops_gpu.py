@@ -1,0 +1,120 @@
+"""GPU: each hand-written kernel through the C ABI against a plain fp32 torch statement of the same op
+(the floating-point kernels keep a torch fp32 reference; the end-to-end path is checked against oracle/)."""
+import numpy as np
+import pytest
+import torch
+
+from knowledge_enhanced_multimodal_retrieval_amd import _lib, engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("m,n,k", [(257, 256, 256), (300, 768, 256), (1000, 1024, 1024), (514, 256, 1024), (63 * 257, 1024, 1024)])
+@pytest.mark.parametrize("epi", [_lib.EPI_BIAS_BF16, _lib.EPI_BIAS_QGELU_BF16, _lib.EPI_BIAS_RESID_F32])
+def test_gemm_epilogues(device, m, n, k, epi):
+    g = torch.Generator().manual_seed(m * 7 + n + k + epi)
+    m_alloc = (m + 255) // 256 * 256
+    a = torch.randn(m_alloc, k, generator=g)
+    w = torch.randn(n, k, generator=g) * (k ** -0.5)
+    bias = torch.randn(n, generator=g)
+    a_bf, w_bf = a.to(torch.bfloat16), w.to(torch.bfloat16)
+    ref = a_bf.float()[:m] @ w_bf.float().T + bias
+    c0 = None
+    if epi == _lib.EPI_BIAS_QGELU_BF16:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    if epi == _lib.EPI_BIAS_RESID_F32:
+        c0 = torch.randn(m_alloc, n, generator=g)
+        ref = ref + c0[:m]
+    c_dev = None if c0 is None else c0.clone().to(device)
+    out = engine.op_gemm(a_bf.to(device), w_bf.to(device), bias.to(device), m, epi, c=c_dev)
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    tol = 2e-2 if epi != _lib.EPI_BIAS_RESID_F32 else 2e-4    # bf16 output rounding vs fp32 output
+    err = (got[:m] - ref).abs()
+    assert float((err / (ref.abs() + 1.0)).max()) < tol
+    if epi == _lib.EPI_BIAS_RESID_F32:                        # rows >= m are never written
+        assert torch.equal(got[m:], c0[m:])
+    else:
+        assert float(got[m:].abs().max()) == 0.0 if m < m_alloc else True
+
+
+def test_gemm_identity_asymmetric(device):
+    """A = I against an asymmetric W catches transposed / permuted fragment maps (cdna guide section 3)."""
+    k = n = 256
+    m_alloc = 256
+    a = torch.eye(m_alloc, k)
+    w = (torch.arange(n * k, dtype=torch.float32).reshape(n, k) % 251) - 125.0        # exact in bf16
+    out = engine.op_gemm(a.to(torch.bfloat16).to(device), w.to(torch.bfloat16).to(device), None, 256, _lib.EPI_BIAS_BF16)
+    torch.cuda.synchronize()
+    assert torch.equal(out.float().cpu(), w.T.contiguous().to(torch.bfloat16).float())
+
+
+def test_gemm_rejects_bad_shapes(device):
+    a = torch.zeros(256, 96, dtype=torch.bfloat16, device=device)
+    w = torch.zeros(128, 96, dtype=torch.bfloat16, device=device)
+    with pytest.raises(RuntimeError, match="K % 64"):
+        engine.op_gemm(a, w, None, 10, _lib.EPI_BIAS_BF16)
+
+
+@pytest.mark.parametrize("width", [256, 512, 768, 1024])
+@pytest.mark.parametrize("out_bf16", [True, False])
+def test_layernorm(device, width, out_bf16):
+    g = torch.Generator().manual_seed(width)
+    rows = 517
+    x = torch.randn(rows, width, generator=g) * 3 + 0.7
+    gamma = 1 + 0.1 * torch.randn(width, generator=g)
+    beta = 0.1 * torch.randn(width, generator=g)
+    ref = torch.nn.functional.layer_norm(x, (width,), gamma, beta, 1e-5)
+    got = engine.op_layernorm(x.to(device), gamma.to(device), beta.to(device), out_bf16).float().cpu()
+    tol = 2e-2 if out_bf16 else 2e-5
+    assert float((got - ref).abs().max()) < tol
+    if not out_bf16:
+        xd = x.to(device)     # in place (ln_pre): y aliases x
+        L = _lib.lib()
+        import ctypes as C
+        _lib.check(L.kemr_op_layernorm(C.c_void_p(xd.data_ptr()), C.c_void_p(gamma.to(device).data_ptr()),
+                                       C.c_void_p(beta.to(device).data_ptr()), C.c_void_p(xd.data_ptr()), rows, width,
+                                       _lib.KEMR_F32, None))
+        torch.cuda.synchronize()
+        assert float((xd.cpu() - ref).abs().max()) < tol
+
+
+def _attention_ref(qkv, batch, t, width, causal):
+    heads = width // 64
+    q, k, v = qkv.float().view(batch, t, 3, heads, 64).permute(2, 0, 3, 1, 4)      # [B,H,T,64]; q already scaled
+    s = q @ k.transpose(-1, -2)
+    if causal:
+        s = s + torch.full((t, t), float("-inf")).triu_(1)
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(batch * t, width)
+
+
+@pytest.mark.parametrize("t,causal", [(17, False), (16, True), (50, False), (77, True), (100, True), (197, False), (257, False)])
+def test_attention(device, t, causal):
+    g = torch.Generator().manual_seed(t)
+    batch, width = 3, 256
+    qkv = torch.randn(batch * t, 3 * width, generator=g)
+    qkv[:, :width] *= 0.125 * 2.0           # pre-scaled queries, logits of a few units
+    qkv_bf = qkv.to(torch.bfloat16)
+    ref = _attention_ref(qkv_bf, batch, t, width, causal)
+    got = engine.op_attention(qkv_bf.to(device), batch, t, width, causal).float().cpu()
+    assert float((got - ref).abs().max()) < 3e-2          # P and the output are rounded to bf16
+    assert float((got - ref).abs().mean()) < 3e-3
+
+
+def test_attention_softmax_spike(device):
+    """One dominant key per query (large logits): exercises the max-subtraction path."""
+    t, batch, width = 257, 1, 256
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(batch * t, 3 * width, generator=g) * 0.1
+    qkv[:, :width] = 0.0
+    qkv[:, 0] = 4.0                          # q[:, d0] = 4 for head 0
+    qkv[:, width] = torch.linspace(-8, 8, t)  # k[:, d0] spread: logits up to 32
+    qkv_bf = qkv.to(torch.bfloat16)
+    ref = _attention_ref(qkv_bf, batch, t, width, False)
+    got = engine.op_attention(qkv_bf.to(device), batch, t, width, False).float().cpu()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) < 3e-2

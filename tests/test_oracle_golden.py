@@ -1,0 +1,113 @@
+"""CPU: the oracle restatements against the golden vectors generated from the reference's own modules
+(tests/golden/make_golden.py; reference files cited in oracle/*.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_ref, fusion_ref, metrics_ref
+
+
+def _json(npz, key):
+    return json.loads(bytes(npz[key]).decode())
+
+
+@pytest.mark.parametrize("tag", ["n256_d768", "n192_d128"])
+def test_metrics_oracle_matches_reference(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, f"metrics_{tag}.npz"))
+    img, q, t = z["image"], z["query"], z["target"]
+    ref = _json(z, "metrics_json")
+    n, d = img.shape
+    # the seeded recipe regenerates the stored embeddings bit for bit
+    img2, q2, t2 = metrics_ref.planted_embeddings(n, d, seed=0)
+    assert np.array_equal(img, img2) and np.array_equal(q, q2) and np.array_equal(t, t2)
+
+    got = metrics_ref.all_retrieval_metrics(q, t, img)
+    assert set(got) == set(ref["all"])
+    for k, v in ref["all"].items():
+        assert got[k] == pytest.approx(v, abs=1e-9), k
+    for k, v in ref["final_0.5_0.5"].items():
+        assert metrics_ref.retrieval_metrics_final(q, t, img)[k] == pytest.approx(v, abs=1e-9)
+    got19 = metrics_ref.retrieval_metrics_final(q, t, img, prefix="F", t2i_weight=0.1, t2t_weight=0.9)
+    assert got19 == pytest.approx(ref["final_0.1_0.9_prefixF"], abs=1e-9)
+    gtrain = metrics_ref.all_retrieval_metrics(q, t, img, compute_recall=False)
+    assert gtrain == pytest.approx(ref["training"], abs=1e-9)
+    gfus = metrics_ref.retrieval_metrics_from_similarity(0.5 * (q @ img.T) + 0.5 * (q @ t.T), prefix="X")
+    assert gfus == pytest.approx(ref["fusion_prefixX"], abs=1e-9)
+    S = metrics_ref.similarity(q, img)
+    assert metrics_ref.retrieval_metrics_from_similarity(S) == pytest.approx(ref["evaluate_retrieval_t2i"], abs=1e-9)
+    # rank / top-k formulations agree with the reference's argsort (no exact ties in these fixtures)
+    assert np.array_equal(metrics_ref.ranks_by_sort(S), z["t2i_ranks"])
+    assert np.array_equal(metrics_ref.ranks_by_count(S), z["t2i_ranks"])
+    assert np.array_equal(metrics_ref.topk(S, 10)[1], z["t2i_top10"])
+
+
+def test_survey_numbers():
+    img, q, t = metrics_ref.planted_embeddings(256, 768, seed=0)
+    m = metrics_ref.retrieval_metrics(q, img, "T2I")
+    assert m["T2I_R@1"] == pytest.approx(2.734375)
+    assert m["T2I_R@10"] == pytest.approx(19.140625)
+    assert m["T2I_Mean_Rank"] == pytest.approx(70.890625)
+
+
+def test_rank_tie_rule():
+    S = np.array([[0.5, 0.5, 0.5, 0.1], [0.2, 0.9, 0.9, 0.9], [1.0, 1.0, 1.0, 1.0], [0.0, 0.3, 0.3, 0.3]], np.float32)
+    assert metrics_ref.ranks_by_sort(S).tolist() == [1, 1, 3, 3]
+    assert metrics_ref.ranks_by_count(S).tolist() == [1, 1, 3, 3]
+    gt = np.array([2, 0, 1, 0])
+    assert np.array_equal(metrics_ref.ranks_by_sort(S, gt), metrics_ref.ranks_by_count(S, gt))
+
+
+def test_sparql_fusion_oracle_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "sparql_fusion.npz"))
+    meta = _json(z, "meta_json")
+    S, uu, res = z["S"], meta["uuids"], meta["results"]
+    np.testing.assert_allclose(fusion_ref.fuse(S, res, uu, uu, "weighted", {"alpha": 0.7, "sparql_weight": 0.3}),
+                               z["weighted_a0.7"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(fusion_ref.weighted(S, res, uu, uu, 0.6, 0.6), z["weighted_a0.6_w0.6"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(fusion_ref.fuse(S, res, uu, uu, "additive", {"delta": 0.5}), z["additive_d0.5"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(fusion_ref.fuse(S, res, uu, uu, "adaptive", {"delta": 0.5}), z["adaptive_d0.5"], rtol=0, atol=1e-7)
+    for name, m in meta["metrics"].items():
+        assert metrics_ref.retrieval_metrics_from_similarity(z[name]) == pytest.approx(m, abs=1e-9)
+    with pytest.raises(ValueError):
+        fusion_ref.fuse(S, res, uu, uu, "nope")
+
+
+def test_fusion_heads_oracle_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "fusion_heads.npz"))
+    for ft in ("linear", "gated", "simple_gated", "simple_gated_with_bias", "bilinear", "cross_attention"):
+        sd = {k.split("__sd__")[1]: z[k] for k in z.files if k.startswith(f"{ft}__sd__")}
+        got = fusion_ref.head_scores(ft, sd, z["q"], z["img"], z["tgt"])
+        np.testing.assert_allclose(got, z[f"{ft}__out"], rtol=1e-4, atol=2e-6, err_msg=ft)
+
+
+def test_engine_linear_fuse(golden_dir):
+    with open(os.path.join(golden_dir, "engine_fuse.json")) as f:
+        g = json.load(f)
+    assert fusion_ref.engine_linear_fuse(g["clip_results"], g["sparql_results"], g["alpha"], g["beta"]) == g["expected"]
+    assert fusion_ref.engine_linear_fuse([], ["x"]) == []
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny-long"])
+def test_clip_oracle_matches_hf_fixture(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, f"clip_hf_{name}.npz"))
+    arch = clip_ref.ARCHS[name]
+    sd = clip_ref.random_state_dict(arch, seed=0)
+    chk = _json(z, "weight_abs_sums")
+    for k, v in chk.items():                      # the seeded weights are the ones the fixture was made with
+        assert float(sd[k].double().abs().sum()) == pytest.approx(v, rel=1e-12), k
+    oi = clip_ref.encode_image(sd, arch, torch.from_numpy(z["pixels"]))
+    ot = clip_ref.encode_text(sd, arch, torch.from_numpy(z["ids"]))
+    np.testing.assert_allclose(oi.numpy(), z["image_features"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(ot.numpy(), z["text_features"], rtol=0, atol=2e-5)
+
+
+def test_synthetic_ids_contract():
+    arch = clip_ref.ARCHS["ViT-L/14"]
+    ids = clip_ref.synthetic_ids(arch, 32)
+    assert ids.shape == (32, 77) and ids.dtype == torch.int32
+    assert (ids[:, 0] == 49406).all()
+    assert ((ids == 49407).sum(dim=1) == 1).all()          # exactly one EOT = row maximum
+    assert (ids.max(dim=1).values == 49407).all()

@@ -1,0 +1,223 @@
+"""GPU: fused similarity + top-k + rank kernels through the C ABI against the numpy oracle
+(oracle/metrics_ref.py, pinned to the reference's metrics.py by tests/golden) and the committed goldens."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from knowledge_enhanced_multimodal_retrieval_amd import _lib, engine, ranking
+from oracle import fusion_ref, metrics_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _panels(q, g, dev, terms, weights=None):
+    qp = engine.build_panel([torch.from_numpy(x).to(dev) for x in q], _lib.SIDE_QUERY, terms, part_scale=weights)
+    gp = engine.build_panel([torch.from_numpy(x).to(dev) for x in g], _lib.SIDE_GALLERY, terms)
+    return qp, gp
+
+
+def _ambiguous(S64, gt, eps):
+    """queries whose ground-truth score has a competitor within eps (rank may legitimately differ by rounding)."""
+    s_gt = S64[np.arange(S64.shape[0]), gt][:, None]
+    d = np.abs(S64 - s_gt)
+    d[np.arange(S64.shape[0]), gt] = np.inf
+    return d.min(axis=1) < eps
+
+
+@pytest.mark.parametrize("terms,tol", [(3, 3e-6), (1, 6e-4)])
+def test_dense_scores_and_pair_scores(device, terms, tol):
+    img, q, t = metrics_ref.planted_embeddings(300, 768, seed=3)
+    qp, gp = _panels([q[:200]], [img], device, terms)
+    S = engine.scores_dense(qp, gp).cpu().numpy()
+    ref = q[:200].astype(np.float64) @ img.astype(np.float64).T
+    assert np.abs(S - ref).max() < tol
+    rows = torch.arange(200, dtype=torch.int32)
+    cols = torch.randint(0, 300, (200,), generator=torch.Generator().manual_seed(1), dtype=torch.int32)
+    ps = engine.pair_scores(qp, gp, rows, cols).cpu().numpy()
+    # bit-identical to the tile kernel: `s_ij > s_gt` comparisons are self-consistent
+    assert np.array_equal(ps, S[rows.numpy(), cols.numpy()])
+
+
+@pytest.mark.parametrize("tag", ["n256_d768", "n192_d128"])
+def test_golden_ranks_and_topk(device, golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, f"metrics_{tag}.npz"))
+    img, q, t = z["image"], z["query"], z["target"]
+    ref = json.loads(bytes(z["metrics_json"]).decode())
+    ranks, top_s, top_i = ranking.ranks_and_topk([q], [img], k=10)
+    S64 = q.astype(np.float64) @ img.astype(np.float64).T
+    amb = _ambiguous(S64, np.arange(len(q)), 2e-6)
+    r = ranks.cpu().numpy()
+    assert np.array_equal(r[~amb], z["t2i_ranks"][~amb]) and np.abs(r - z["t2i_ranks"]).max() <= 1
+    got = ranking.metrics_from_ranks(ranks)
+    for key in ("R@1", "R@5", "R@10", "R@20", "MRR", "Mean_Rank"):
+        assert got[key] == pytest.approx(ref["all"][f"T2I_{key}"], abs=1e-6 if not amb.any() else 0.5), key
+    # top-10 sets identical wherever the 10th/11th margin is resolvable
+    order = np.argsort(-S64, axis=1, kind="stable")
+    margin = np.take_along_axis(S64, order[:, 9:10], 1) - np.take_along_axis(S64, order[:, 10:11], 1)
+    ok = margin[:, 0] > 2e-6
+    ti = top_i.cpu().numpy()
+    assert np.array_equal(np.sort(ti[ok], axis=1), np.sort(z["t2i_top10"][ok], axis=1))
+    np.testing.assert_allclose(top_s.cpu().numpy(), np.take_along_axis(S64, ti.astype(np.int64), 1), atol=3e-6)
+
+
+def test_fused_t2i_t2t_weights(device):
+    img, q, t = metrics_ref.planted_embeddings(256, 768, seed=0)
+    for wi, wt in ((0.5, 0.5), (0.1, 0.9)):
+        ranks, _, _ = ranking.ranks_and_topk([q, q], [img, t], weights=[wi, wt], k=10)
+        S64 = wi * (q.astype(np.float64) @ img.astype(np.float64).T) + wt * (q.astype(np.float64) @ t.astype(np.float64).T)
+        amb = _ambiguous(S64, np.arange(256), 3e-6)
+        ref = metrics_ref.ranks_by_count(S64)
+        r = ranks.cpu().numpy()
+        assert np.array_equal(r[~amb], ref[~amb]) and np.abs(r - ref).max() <= 1
+        got = ranking.metrics_from_ranks(ranks)
+        want = metrics_ref.retrieval_metrics_final(q, t, img, t2i_weight=wi, t2t_weight=wt)
+        for k_, v in want.items():
+            assert got[k_] == pytest.approx(v, abs=0.8 if amb.any() else 1e-6)
+
+
+def test_row_gate(device):
+    img, q, t = metrics_ref.planted_embeddings(200, 128, seed=5)
+    gate = np.random.default_rng(0).uniform(0.05, 0.95, 200).astype(np.float32)
+    ranks, top_s, top_i = ranking.ranks_and_topk([q, q], [img, t], row_gate=[gate, 1 - gate], k=5)
+    S64 = gate[:, None].astype(np.float64) * (q.astype(np.float64) @ img.astype(np.float64).T) + \
+        (1 - gate)[:, None].astype(np.float64) * (q.astype(np.float64) @ t.astype(np.float64).T)
+    amb = _ambiguous(S64, np.arange(200), 3e-6)
+    assert np.array_equal(ranks.cpu().numpy()[~amb], metrics_ref.ranks_by_count(S64)[~amb])
+
+
+@pytest.mark.parametrize("k", [1, 10, 20, 32])
+@pytest.mark.parametrize("terms", [1, 3])
+def test_ragged_sizes_offsets_and_shard_merge(device, k, terms):
+    rng = np.random.default_rng(k)
+    nq, ng, d = 300, 1000, 96          # nothing a multiple of 128, d padded to 128
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    g = rng.standard_normal((ng, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    gt = rng.integers(0, ng, nq).astype(np.int32)
+    qp, gp = _panels([q], [g], device, terms)
+    S = engine.scores_dense(qp, gp).cpu().numpy()                 # the kernel's own scores: exact expectations
+    sgt = engine.pair_scores(qp, gp, torch.arange(nq, dtype=torch.int32), torch.from_numpy(gt))
+    ahead = torch.zeros(nq, dtype=torch.int32, device=device)
+    top_s, top_i = engine.sim_topk(qp, gp, k, 0, torch.from_numpy(gt), sgt, ahead)
+    exp_s, exp_i = metrics_ref.topk(S, k)
+    assert np.array_equal(top_i.cpu().numpy(), exp_i)
+    assert np.array_equal(top_s.cpu().numpy(), exp_s)
+    assert np.array_equal(ahead.cpu().numpy() + 1, metrics_ref.ranks_by_count(S, gt))
+
+    # three uneven shards with global ids, merged: identical to the single-gallery answer
+    bounds = [0, 130, 640, ng]
+    parts_s, parts_i = [], []
+    ahead2 = torch.zeros(nq, dtype=torch.int32, device=device)
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        gps = engine.build_panel([torch.from_numpy(g[lo:hi]).to(device)], _lib.SIDE_GALLERY, terms)
+        s_, i_ = engine.sim_topk(qp, gps, k, lo, torch.from_numpy(gt), sgt, ahead2)
+        parts_s.append(s_)
+        parts_i.append(i_)
+    ms, mi = engine.topk_merge(torch.stack(parts_s, 1), torch.stack(parts_i, 1), k)
+    assert np.array_equal(mi.cpu().numpy(), exp_i) and np.array_equal(ms.cpu().numpy(), exp_s)
+    assert np.array_equal(ahead2.cpu().numpy(), ahead.cpu().numpy())
+
+
+def test_exact_ties_lower_index_first(device):
+    rng = np.random.default_rng(9)
+    base = rng.standard_normal((40, 64)).astype(np.float32)
+    g = np.concatenate([base, base, base[:20]], 0)               # every row appears 2-3 times: exact score ties
+    q = rng.standard_normal((33, 64)).astype(np.float32)
+    gt = rng.integers(0, len(g), 33).astype(np.int32)
+    qp, gp = _panels([q], [g], device, 3)
+    S = engine.scores_dense(qp, gp).cpu().numpy()
+    assert (S[:, :40] == S[:, 40:80]).all()
+    sgt = engine.pair_scores(qp, gp, torch.arange(33, dtype=torch.int32), torch.from_numpy(gt))
+    ahead = torch.zeros(33, dtype=torch.int32, device=device)
+    top_s, top_i = engine.sim_topk(qp, gp, 10, 0, torch.from_numpy(gt), sgt, ahead)
+    assert np.array_equal(top_i.cpu().numpy(), metrics_ref.topk(S, 10)[1])
+    assert np.array_equal(ahead.cpu().numpy() + 1, metrics_ref.ranks_by_count(S, gt))
+
+
+def test_k_larger_than_gallery_pads(device):
+    q = np.eye(4, 64, dtype=np.float32)
+    g = np.eye(3, 64, dtype=np.float32)
+    qp, gp = _panels([q], [g], device, 1)
+    s, i = engine.sim_topk(qp, gp, 5)
+    i = i.cpu().numpy()
+    assert (i[:, 3:] == -1).all() and np.isinf(s.cpu().numpy()[:, 3:]).all()
+    assert i[0, 0] == 0 and i[1, 0] == 1 and i[2, 0] == 2 and sorted(i[3, :3]) == [0, 1, 2]
+    with pytest.raises(RuntimeError, match="k=40"):
+        engine.sim_topk(qp, gp, 40)
+
+
+def test_sparql_bonus_matches_oracle(device, golden_dir):
+    z = np.load(os.path.join(golden_dir, "sparql_fusion.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    uu, res = meta["uuids"], meta["results"]
+    n = len(uu)
+    img, q, t = metrics_ref.planted_embeddings(n, 128, seed=2)
+    rows, cols, sizes = fusion_ref.hit_pairs(res, uu, uu)
+    S = metrics_ref.similarity(q, img)
+    for strategy in ("additive", "adaptive"):
+        vals = np.full(len(rows), 0.5, np.float32) if strategy == "additive" else \
+            np.asarray([0.5 * fusion_ref.omega_of_size(int(s)) for s in sizes], np.float32)
+        order = np.lexsort((cols, rows))
+        r_, c_, v_ = rows[order], cols[order], vals[order]
+        ptr = np.zeros(n + 1, np.int32)
+        np.add.at(ptr, r_ + 1, 1)
+        ptr = np.cumsum(ptr).astype(np.int32)
+        ranks, top_s, top_i = ranking.ranks_and_topk([q], [img], k=10, bonus=(ptr, c_.astype(np.int32), v_))
+        want = fusion_ref.fuse(S.astype(np.float64), res, uu, uu, strategy, {"delta": 0.5})
+        amb = _ambiguous(want, np.arange(n), 3e-6)
+        assert np.array_equal(ranks.cpu().numpy()[~amb], metrics_ref.ranks_by_count(want)[~amb])
+        np.testing.assert_allclose(top_s.cpu().numpy()[:, 0], want.max(axis=1), atol=3e-6)
+
+
+def test_rank_dense_matches_oracle(device):
+    rng = np.random.default_rng(4)
+    S = rng.standard_normal((77, 1003)).astype(np.float32)
+    S[:, 500:600] = S[:, 100:200]                                   # exact ties
+    gt = rng.integers(0, 1003, 77).astype(np.int32)
+    for k in (10, 20):
+        ranks, top_s, top_i = ranking.ranks_of_matrix(S, k=k, gt_idx=gt)
+        assert np.array_equal(ranks.cpu().numpy(), metrics_ref.ranks_by_count(S, gt))
+        assert np.array_equal(top_i.cpu().numpy(), metrics_ref.topk(S, k)[1])
+        assert np.array_equal(top_s.cpu().numpy(), metrics_ref.topk(S, k)[0])
+    sq = rng.standard_normal((64, 64)).astype(np.float32)
+    ranks, _, _ = ranking.ranks_of_matrix(sq)
+    assert np.array_equal(ranks.cpu().numpy(), metrics_ref.ranks_by_sort(sq))
+
+
+def test_full_gallery_properties(device):
+    """BASELINE sizes (43k gallery, D=768): no oracle at this size; check size-independent properties."""
+    n, d, nq, k = 43000, 768, 1024, 10
+    g = torch.Generator(device="cpu").manual_seed(0)
+    gal = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=-1).to(device)
+    qry = torch.nn.functional.normalize(gal[:nq] + 0.04 * torch.randn(nq, d, generator=g).to(device), dim=-1)
+    qp = engine.build_panel([qry], _lib.SIDE_QUERY, 1)
+    gp = engine.build_panel([gal], _lib.SIDE_GALLERY, 1)
+    gt = torch.arange(nq, dtype=torch.int32, device=device)
+    sgt = engine.pair_scores(qp, gp, gt, gt)
+    ahead = torch.zeros(nq, dtype=torch.int32, device=device)
+    top_s, top_i = engine.sim_topk(qp, gp, k, 0, gt, sgt, ahead)
+    # (1) every reported score is the pair score of its id, lists are sorted by (score desc, id asc)
+    rows = torch.arange(nq, device=device).repeat_interleave(k).int()
+    assert torch.equal(engine.pair_scores(qp, gp, rows, top_i.reshape(-1)).view(nq, k), top_s)
+    assert bool((top_s[:, :-1] >= top_s[:, 1:]).all())
+    # (2) rank <= k  <=>  ground truth inside the top-k list; rank 1 <=> it leads the list
+    in_list = (top_i == gt[:, None]).any(dim=1)
+    assert torch.equal(in_list, ahead < k)
+    assert torch.equal(top_i[:, 0] == gt, ahead == 0)
+    assert float((ahead == 0).float().mean()) > 0.9             # the planted signal is strong
+    # (3) 8-way sharding with global ids + merge reproduces the single-gallery answer (config 4's data path)
+    per = (n + 7) // 8
+    ps, pi = [], []
+    ahead8 = torch.zeros(nq, dtype=torch.int32, device=device)
+    for r in range(8):
+        lo, hi = r * per, min(n, (r + 1) * per)
+        gps = engine.build_panel([gal[lo:hi]], _lib.SIDE_GALLERY, 1)
+        s_, i_ = engine.sim_topk(qp, gps, k, lo, gt, sgt, ahead8)
+        ps.append(s_)
+        pi.append(i_)
+    ms, mi = engine.topk_merge(torch.stack(ps, 1), torch.stack(pi, 1), k)
+    assert torch.equal(mi, top_i) and torch.equal(ms, top_s) and torch.equal(ahead8, ahead)
