@@ -73,6 +73,10 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m knowledge_enhanced_multimodal_retrieval_amd.build` "
                 "(hipcc, gfx950). There is no CPU fallback for this path.")
+        # torch must be imported BEFORE the dlopen: PyTorch-ROCm ships its own libamdhip64.so, and libkemr.so's
+        # DT_NEEDED libamdhip64.so.7 binds to whichever copy is already in the process.  Loaded the other way round the
+        # process ends up with two HIP runtimes and every HIP call of libkemr fails with hipErrorNoDevice.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             try:

@@ -215,9 +215,9 @@ def sim_topk(qp: Panel, gp: Panel, k: int, gallery_offset: int = 0,
             raise RuntimeError("sim_topk: ahead must be a contiguous int32 tensor on the panel's device")
     b_ptr = b_col = b_val = None
     if bonus is not None:
-        b_ptr, b_col, b_val = (bonus[0].to(device=dev, dtype=torch.int32).contiguous(),
-                               bonus[1].to(device=dev, dtype=torch.int32).contiguous(),
-                               bonus[2].to(device=dev, dtype=torch.float32).contiguous())
+        b_ptr, b_col, b_val = (torch.as_tensor(bonus[0]).to(device=dev, dtype=torch.int32).contiguous(),
+                               torch.as_tensor(bonus[1]).to(device=dev, dtype=torch.int32).contiguous(),
+                               torch.as_tensor(bonus[2]).to(device=dev, dtype=torch.float32).contiguous())
         if b_ptr.numel() != nq + 1:
             raise RuntimeError("sim_topk: bonus row pointer must have nq + 1 entries")
     with torch.cuda.device(dev):

@@ -76,8 +76,9 @@ def test_layernorm(device, width, out_bf16):
         xd = x.to(device)     # in place (ln_pre): y aliases x
         L = _lib.lib()
         import ctypes as C
-        _lib.check(L.kemr_op_layernorm(C.c_void_p(xd.data_ptr()), C.c_void_p(gamma.to(device).data_ptr()),
-                                       C.c_void_p(beta.to(device).data_ptr()), C.c_void_p(xd.data_ptr()), rows, width,
+        gd, bd = gamma.to(device), beta.to(device)      # keep the device copies alive across the call
+        _lib.check(L.kemr_op_layernorm(C.c_void_p(xd.data_ptr()), C.c_void_p(gd.data_ptr()),
+                                       C.c_void_p(bd.data_ptr()), C.c_void_p(xd.data_ptr()), rows, width,
                                        _lib.KEMR_F32, None))
         torch.cuda.synchronize()
         assert float((xd.cpu() - ref).abs().max()) < tol
