@@ -127,7 +127,8 @@ int kemr_panel_build(const float* const* parts_dev, const float* part_scale, con
 /* Fused score + per-query top-k + rank of a ground-truth candidate.
  *   q_panel [nq,kdim], g_panel [ng,kdim]
  *   gallery_offset : global id of gallery row 0 (sharded galleries); ids written are global
- *   k <= 32; top_scores/top_idx [nq,k] sorted (score desc, id asc), padded with -inf / -1
+ *   k <= 32; top_scores/top_idx [nq,k] sorted (score desc, id asc), padded with -inf / -1;
+ *   k == 0 = rank only (top_* may be NULL, the ground truth is then required)
  *   gt_idx  : optional int32 [nq] GLOBAL candidate id of each query's ground truth
  *   gt_score: optional fp32 [nq]; score of (query, gt) as produced by kemr_pair_scores
  *   ahead   : optional int32 [nq]; += #{j in this gallery : s_ij > s_gt or (s_ij == s_gt and id_j < gt)}
@@ -166,6 +167,11 @@ int kemr_scores_dense(const void* q_panel_dev, int nq, const void* g_panel_dev, 
  * evaluate_retrieval (eval/fusion.py:6-20), evaluator_fusion.py:126.  Either output pair may be NULL. */
 int kemr_rank_dense(const float* scores_dev, int nq, int ng, int64_t ld, const int32_t* gt_idx_dev,
                     int32_t* ahead_dev, int k, float* top_scores_dev, int32_t* top_idx_dev, void* stream);
+
+/* Learned "linear" fusion head in eval mode (reference src/clip/model/fusion_model.py:25-48):
+ * out[i] = w1 . relu(W0 . [t2i[i], t2t[i]] + b0) + b1 over n score pairs (W0 fp32 [hidden,2], b0/w1 fp32 [hidden]). */
+int kemr_linear_head(const float* t2i_dev, const float* t2t_dev, int64_t n, const float* w0_dev, const float* b0_dev,
+                     const float* w1_dev, float b1, int hidden, float* out_dev, void* stream);
 
 /* Optional per-kernel-class timing with hipEvents recorded on the launch stream (bench.py's roofline line).
  * Classes: 0 GEMM, 1 LayerNorm, 2 attention, 3 embed/tail, 4 similarity tile kernel.  Not thread-safe;

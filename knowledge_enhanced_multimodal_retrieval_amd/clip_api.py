@@ -1,0 +1,80 @@
+"""`clip.load` / `clip.tokenize` / `clip.available_models` of the third-party ``clip`` package, served by this build.
+
+The reference imports ``clip`` everywhere it touches the model (/root/reference/src/clip/model/clip_model.py:7,41;
+src/clip/eval/evaluator_baseline.py:19,112; src/clip/eval/evaluator.py:18,126); the repo-root ``clip/`` package
+re-exports these functions so those imports resolve to the HIP engine.
+
+Weights: upstream ``clip.load(name)`` downloads a checkpoint, which is impossible offline.  Here
+* ``name`` may be a path to a state-dict file (``.pt`` with ``model_state_dict`` / ``state_dict`` / bare dict,
+  loaded with ``weights_only=True``; or ``.safetensors``), optionally ``"ViT-L/14@/path/file"``;
+* or a known model name: ``$KEMR_CLIP_WEIGHTS/<name with / -> ->.pt|.safetensors`` is used when present;
+* otherwise the architecture is built with seeded random weights and a warning says so (synthetic-data runs).
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from typing import List, Tuple, Union
+
+import torch
+
+from .clip_module import CLIP, build_model
+from .config import ARCHS, get_arch
+from .preprocess import ClipPreprocess
+from .tokenizer import tokenize  # noqa: F401  (re-exported)
+
+_PUBLIC = ("ViT-B/32", "ViT-B/16", "ViT-L/14")
+
+
+def available_models() -> List[str]:
+    return list(_PUBLIC)
+
+
+def read_state_dict(path: str) -> dict:
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path)
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    for key in ("model_state_dict", "state_dict"):
+        if isinstance(ckpt, dict) and key in ckpt:
+            return ckpt[key]
+    return ckpt
+
+
+def _weights_for(name: str):
+    root = os.environ.get("KEMR_CLIP_WEIGHTS")
+    if not root:
+        return None
+    stem = name.replace("/", "-")
+    for ext in (".safetensors", ".pt"):
+        p = os.path.join(root, stem + ext)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def load(name: str, device: Union[str, torch.device] = "cuda" if torch.cuda.is_available() else "cpu",
+         jit: bool = False, download_root: str = None) -> Tuple[CLIP, ClipPreprocess]:
+    if jit:
+        raise RuntimeError("clip.load(jit=True) is not supported by the HIP engine")
+    path = None
+    if "@" in name:
+        name, path = name.split("@", 1)
+    elif os.path.isfile(name):
+        raise RuntimeError("pass a checkpoint as '<model name>@<path>' so that the architecture is known")
+    if name not in ARCHS:
+        raise RuntimeError(f"Model {name} not found; available models = {available_models()}")
+    path = path or _weights_for(name)
+    seed_state = torch.random.get_rng_state()
+    torch.manual_seed(0)                     # reproducible random init when no weights are available
+    try:
+        model = build_model(name, device="cpu")
+    finally:
+        torch.random.set_rng_state(seed_state)
+    if path:
+        model.load_state_dict(read_state_dict(path), strict=True)
+    else:
+        warnings.warn(f"clip.load({name!r}): no checkpoint available offline (set KEMR_CLIP_WEIGHTS or pass "
+                      f"'{name}@/path/to/state_dict.pt'); using seeded RANDOM weights", RuntimeWarning, stacklevel=2)
+    model = model.to(device).eval()
+    return model, ClipPreprocess(get_arch(name).image_size)

@@ -90,9 +90,44 @@ __global__ __launch_bounds__(256) void rank_dense_kernel(const float* __restrict
     }
 }
 
+// Learned "linear" fusion head (reference fusion_model.py:25-48, eval mode): out = w1 . relu(W0 . [t2i, t2t] + b0) + b1
+// per (query, candidate) pair.  Element-wise over the two dense score matrices; the tiny MLP lives in LDS.
+__global__ __launch_bounds__(256) void linear_head_kernel(const float* __restrict__ t2i, const float* __restrict__ t2t,
+                                                          long long n, const float* __restrict__ w0,
+                                                          const float* __restrict__ b0, const float* __restrict__ w1,
+                                                          float b1, int hidden, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* hw = (float4*)smem;                    // per hidden unit: (w0[h][0], w0[h][1], b0[h], w1[h])
+    for (int h = threadIdx.x; h < hidden; h += 256) hw[h] = make_float4(w0[2 * h], w0[2 * h + 1], b0[h], w1[h]);
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float a = t2i[i], b = t2t[i];
+        float acc = b1;
+        for (int h = 0; h < hidden; ++h) {
+            const float4 w = hw[h];
+            acc = fmaf(w.w, fmaxf(fmaf(w.x, a, fmaf(w.y, b, w.z)), 0.f), acc);
+        }
+        out[i] = acc;
+    }
+}
+
 }  // namespace kemr
 
 using namespace kemr;
+
+extern "C" int kemr_linear_head(const float* t2i_dev, const float* t2t_dev, int64_t n, const float* w0_dev,
+                                const float* b0_dev, const float* w1_dev, float b1, int hidden, float* out_dev,
+                                void* stream) {
+    if (n == 0) return KEMR_OK;
+    if (!t2i_dev || !t2t_dev || !w0_dev || !b0_dev || !w1_dev || !out_dev || n < 0 || hidden < 1 || hidden > 2048)
+        KEMR_FAIL(KEMR_ERR_INVALID, "linear_head: bad argument");
+    long long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(linear_head_kernel, dim3((unsigned)blocks), dim3(256), (size_t)hidden * 16, (hipStream_t)stream,
+                       t2i_dev, t2t_dev, (long long)n, w0_dev, b0_dev, w1_dev, b1, hidden, out_dev);
+    KEMR_CHECK_LAUNCH("linear_head_kernel");
+    return KEMR_OK;
+}
 
 extern "C" int kemr_rank_dense(const float* scores_dev, int nq, int ng, int64_t ld, const int32_t* gt_idx_dev,
                                int32_t* ahead_dev, int k, float* top_scores_dev, int32_t* top_idx_dev, void* stream) {

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void sim_kernel(const SimParams p) {
     int li[KMAX];
 #pragma unroll
     for (int i = 0; i < KMAX; ++i) { ls[i] = -INFINITY; li[i] = -1; }
+    const bool want_topk = p.part_scores != nullptr;      // rank-only calls (k == 0) skip the list maintenance
     int gt = -1, cnt = 0;
     float sgt = 0.f;
     int bcur = 0, bend = 0, next_col = INT_MAX;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void sim_kernel(const SimParams p) {
                         next_col = bcur < bend ? p.bcol[bcur] : INT_MAX;
                     }
                     if (gid != gt) cnt += ranks_before(sc, gid, sgt, gt) ? 1 : 0;
-                    if (sc > ls[KMAX - 1]) topk_insert<KMAX>(ls, li, sc, gid);
+                    if (want_topk && sc > ls[KMAX - 1]) topk_insert<KMAX>(ls, li, sc, gid);
                 }
             }
         }
@@ -376,7 +377,7 @@ static int sim_chunks(int nq, int ng, int* tiles_per_chunk) {
 }
 
 extern "C" size_t kemr_sim_workspace_bytes(int nq, int ng, int k) {
-    if (nq <= 0 || ng <= 0 || k <= 0) return 0;
+    if (nq <= 0 || ng <= 0 || k <= 0) return 0;     // k == 0: rank only, no partial lists
     int tpc;
     const int nchunks = sim_chunks(nq, ng, &tpc);
     return (size_t)round_up((int64_t)nq * nchunks * k * 8, 256);
@@ -407,27 +408,29 @@ extern "C" int kemr_sim_topk(const void* q_panel_dev, int nq, const void* g_pane
                              const int32_t* bonus_rowptr_dev, const int32_t* bonus_col_dev, const float* bonus_val_dev,
                              void* workspace_dev, size_t workspace_bytes, void* stream) {
     KEMR_TRY(check_panels(q_panel_dev, nq, g_panel_dev, ng, kdim));
-    if (k < 1 || k > 32) KEMR_FAIL(KEMR_ERR_INVALID, "sim_topk: k=%d not in 1..32", k);
-    if (!top_scores_dev || !top_idx_dev) KEMR_FAIL(KEMR_ERR_INVALID, "sim_topk: null output");
+    if (k < 0 || k > 32) KEMR_FAIL(KEMR_ERR_INVALID, "sim_topk: k=%d not in 0..32", k);
+    if (k > 0 && (!top_scores_dev || !top_idx_dev)) KEMR_FAIL(KEMR_ERR_INVALID, "sim_topk: null output");
+    if (k == 0 && !gt_idx_dev) KEMR_FAIL(KEMR_ERR_INVALID, "sim_topk: k == 0 (rank only) needs a ground truth");
     if ((gt_idx_dev != nullptr) != (gt_score_dev != nullptr) || (gt_idx_dev != nullptr) != (ahead_dev != nullptr))
         KEMR_FAIL(KEMR_ERR_INVALID, "sim_topk: gt_idx, gt_score and ahead must be given together");
     if ((bonus_rowptr_dev != nullptr) != (bonus_col_dev != nullptr) || (bonus_rowptr_dev != nullptr) != (bonus_val_dev != nullptr))
         KEMR_FAIL(KEMR_ERR_INVALID, "sim_topk: bonus CSR arrays must be given together");
     if (gallery_offset < 0 || gallery_offset + ng > 0x7fffffffLL) KEMR_FAIL(KEMR_ERR_INVALID, "sim_topk: candidate ids exceed int32");
     const size_t need = kemr_sim_workspace_bytes(nq, ng, k);
-    if (!workspace_dev || workspace_bytes < need) KEMR_FAIL(KEMR_ERR_WORKSPACE, "sim_topk: workspace %zu < %zu bytes", workspace_bytes, need);
+    if (k > 0 && (!workspace_dev || workspace_bytes < need)) KEMR_FAIL(KEMR_ERR_WORKSPACE, "sim_topk: workspace %zu < %zu bytes", workspace_bytes, need);
     SimParams p{};
     p.Q = (const bf16_t*)q_panel_dev; p.G = (const bf16_t*)g_panel_dev; p.nq = nq; p.ng = ng; p.kdim = (int)kdim;
     p.goff = gallery_offset; p.k = k;
     p.nchunks = sim_chunks(nq, ng, &p.tiles_per_chunk);
     p.g_tiles = (ng + ST - 1) / ST;
-    p.part_scores = (float*)workspace_dev;
-    p.part_idx = (int32_t*)((char*)workspace_dev + (size_t)nq * p.nchunks * k * 4);
+    p.part_scores = k > 0 ? (float*)workspace_dev : nullptr;
+    p.part_idx = k > 0 ? (int32_t*)((char*)workspace_dev + (size_t)nq * p.nchunks * k * 4) : nullptr;
     p.gt_idx = gt_idx_dev; p.gt_score = gt_score_dev; p.ahead = ahead_dev;
     p.brow = bonus_rowptr_dev; p.bcol = bonus_col_dev; p.bval = bonus_val_dev;
     hipStream_t s = (hipStream_t)stream;
     if (k <= 10) KEMR_TRY((launch_sim<10, false>(p, s)));
     else KEMR_TRY((launch_sim<32, false>(p, s)));
+    if (k == 0) return KEMR_OK;
     hipLaunchKernelGGL(topk_merge_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, p.part_scores, p.part_idx, nq, p.nchunks * k, k,
                        top_scores_dev, top_idx_dev);
     KEMR_CHECK_LAUNCH("topk_merge_kernel");

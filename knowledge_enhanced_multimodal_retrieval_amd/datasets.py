@@ -1,0 +1,93 @@
+"""Host-side input contract of the evaluators (reference: /root/reference/src/clip/datasets/clip_dataset.py:81-132,
+176-180): a sample is ``(image f32[3,S,S], query_text, target_text, uuid)``, a batch is
+``(f32[B,3,S,S], list[str], list[str], list[str])``.  ``CLIPEvalDatasetHF`` wraps a HuggingFace split the same way
+(word-truncation to 150 words, zero image when decoding fails); ``SyntheticRetrievalDataset`` provides the same
+contract from a seed so that every entry point runs offline."""
+from __future__ import annotations
+
+import logging
+from typing import List
+
+import torch
+from torch.utils.data import Dataset
+
+logger = logging.getLogger(__name__)
+
+
+def truncate_words(text: str, max_words: int) -> str:
+    words = text.split()
+    return " ".join(words[:max_words]) if len(words) > max_words else text
+
+
+class CLIPEvalDatasetHF(Dataset):
+    """Evaluation dataset over a HuggingFace split with columns image / query_text / target_text / uuid."""
+
+    def __init__(self, hf_dataset, preprocessor=None, max_text_length: int = 150, image_size: int = 224):
+        self.dataset, self.preprocessor = hf_dataset, preprocessor
+        self.max_text_length, self.image_size = max_text_length, image_size
+        logger.info(f"Evaluation dataset initialized: {len(self.dataset)} samples")
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def _truncate_text(self, text: str) -> str:
+        return truncate_words(text, self.max_text_length)
+
+    def __getitem__(self, idx):
+        sample = self.dataset[idx]
+        try:
+            image = sample["image"]
+            if image.mode != "RGB":
+                image = image.convert("RGB")
+            if self.preprocessor:
+                image = self.preprocessor(image)
+        except Exception as e:  # undecodable image -> zero image, like the reference (clip_dataset.py:120-125)
+            logger.error(f"Error loading image {sample.get('uuid', idx)}: {e}")
+            if self.preprocessor:
+                image = torch.zeros(3, self.image_size, self.image_size)
+            else:
+                from PIL import Image
+                image = Image.new("RGB", (self.image_size, self.image_size))
+        return (image, self._truncate_text(sample["query_text"]), self._truncate_text(sample["target_text"]),
+                sample["uuid"])
+
+
+CLIPEvaluationDataset = CLIPEvalDatasetHF
+
+_WORDS = ("amphora vase bronze marble portrait landscape oil canvas roman greek medieval baroque gilded wooden panel "
+          "statue relief fresco mosaic coin sword helmet textile manuscript folio saint king queen river harbour "
+          "ceramic glazed terracotta figure seated standing holding crown dated century workshop attributed school "
+          "museum collection fragment inscription").split()
+
+
+class SyntheticRetrievalDataset(Dataset):
+    """Seeded stand-in for the (unavailable offline) ``xuemduan/reevaluate-image-text-pairs`` split: normalised-pixel
+    noise images and word-salad query / target texts that share a few item-specific words."""
+
+    def __init__(self, n: int, image_size: int = 224, seed: int = 42):
+        self.n, self.image_size, self.seed = n, image_size, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, idx):
+        g = torch.Generator().manual_seed(self.seed * 1_000_003 + idx)
+        image = torch.randn(3, self.image_size, self.image_size, generator=g)
+        pick = lambda k: [_WORDS[int(i)] for i in torch.randint(0, len(_WORDS), (k,), generator=g)]
+        shared = pick(4)
+        query = " ".join(shared[:2] + pick(int(torch.randint(3, 12, (1,), generator=g))))
+        target = " ".join(shared + pick(int(torch.randint(10, 40, (1,), generator=g))))
+        return image, query, target, f"synthetic-{idx:06d}"
+
+
+def collate_fn_eval(batch):
+    images, queries, targets, uuids = zip(*batch)
+    return torch.stack(images, dim=0), list(queries), list(targets), list(uuids)
+
+
+collate_fn_train = collate_fn_eval
+
+
+def collate_fn_eval_texts(batch):
+    queries, targets = zip(*batch)
+    return list(queries), list(targets)

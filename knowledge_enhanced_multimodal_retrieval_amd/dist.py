@@ -1,0 +1,115 @@
+"""Gallery sharded over the GPUs of one node: one process per GPU, RCCL through ``torch.distributed``.
+
+The reference's eval / search path is single-device; this is new design for BASELINE
+config 4.  Gallery items are independent, so each rank encodes and keeps its own contiguous shard resident; a search
+has exactly one exchange step:
+
+1. ``all_gather`` of the query embeddings (each rank encoded 1/world of the query batch; 128 x 768 fp32 per rank at
+   Q = 1024 -- KB-scale, latency-bound, the xGMI links are never the limit),
+2. local fused similarity + top-k against the own shard with global candidate ids (``gallery_offset``),
+3. ``all_gather`` of the per-shard candidates ([Q, k] scores + ids), merged by ``kemr_topk_merge`` on every rank.
+
+Ranks of a ground truth add two tiny reductions: the owner shard computes the ground-truth score
+(``kemr_pair_scores``; ``all_reduce(sum)`` with zeros elsewhere) and the per-shard ``ahead`` counts are summed.
+
+The compute calls are taken from an ``ops`` namespace (default: the HIP-backed ``engine`` module) so that the
+collective plumbing can be exercised with gloo on CPU-only machines in tests; the product path always uses ``engine``.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import _lib, engine, ranking
+
+
+def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous split: rank r owns global ids [lo, hi) with ceil(n / world) items per rank (the last may be short)."""
+    per = (n + world - 1) // world
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def _world(group) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
+    """Concatenate equally shaped per-rank tensors along dim 0 (single fused all-gather)."""
+    world, _ = _world(group)
+    if world == 1:
+        return x
+    x = x.contiguous()
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x, group=group)
+    return out
+
+
+class ShardedGallery:
+    """This rank's shard of the gallery, packed for the fused similarity kernel."""
+
+    def __init__(self, local_parts: Sequence[torch.Tensor], n_total: int, precision: str = "fp32x3", group=None, ops=engine):
+        self.group, self.ops = group, ops
+        self.world, self.rank = _world(group)
+        self.n_total = n_total
+        self.lo, self.hi = shard_bounds(n_total, self.world, self.rank)
+        if local_parts[0].shape[0] != self.hi - self.lo:
+            raise ValueError(f"rank {self.rank} owns ids [{self.lo}, {self.hi}) but got {local_parts[0].shape[0]} rows")
+        self.terms = ranking.PRECISION_TERMS[precision]
+        self.nparts = len(local_parts)
+        self.panel = ops.build_panel(list(local_parts), _lib.SIDE_GALLERY, self.terms) if self.hi > self.lo else None
+
+    def _query_panel(self, local_query_parts, weights, row_gate):
+        qs = [all_gather_rows(q, self.group) for q in local_query_parts]
+        gates = None
+        if row_gate is not None:
+            gates = [None if g is None else all_gather_rows(g.reshape(-1, 1), self.group).reshape(-1) for g in row_gate]
+        return self.ops.build_panel(qs, _lib.SIDE_QUERY, self.terms, part_scale=weights, row_scale=gates), qs[0].shape[0]
+
+    def search(self, local_query_parts: Sequence[torch.Tensor], weights: Optional[Sequence[float]] = None, k: int = 10,
+               row_gate=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Every rank passes its slice of the query batch (same row count on all ranks) and receives the merged
+        top-k of the WHOLE batch against the WHOLE gallery: (scores [Q, k], global ids [Q, k])."""
+        qp, nq = self._query_panel(local_query_parts, weights, row_gate)
+        dev = local_query_parts[0].device
+        if self.panel is not None:
+            s, i = self.ops.sim_topk(qp, self.panel, k, self.lo)
+        else:
+            s = torch.full((nq, k), float("-inf"), dtype=torch.float32, device=dev)
+            i = torch.full((nq, k), -1, dtype=torch.int32, device=dev)
+        if self.world == 1:
+            return s, i
+        ss = all_gather_rows(s.unsqueeze(0), self.group)          # [world, Q, k]
+        ii = all_gather_rows(i.unsqueeze(0), self.group)
+        return self.ops.topk_merge(ss.permute(1, 0, 2).contiguous(), ii.permute(1, 0, 2).contiguous(), k)
+
+    def ranks(self, local_query_parts: Sequence[torch.Tensor], local_gt: torch.Tensor,
+              weights: Optional[Sequence[float]] = None, k: int = 10, row_gate=None
+              ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """As ``search`` plus the 1-based rank of each query's ground-truth candidate (GLOBAL id in ``local_gt``)."""
+        qp, nq = self._query_panel(local_query_parts, weights, row_gate)
+        dev = local_query_parts[0].device
+        gt = all_gather_rows(local_gt.to(device=dev, dtype=torch.int32).reshape(-1, 1), self.group).reshape(-1)
+        mine = (gt >= self.lo) & (gt < self.hi)
+        sgt = torch.zeros(nq, dtype=torch.float32, device=dev)
+        if self.panel is not None and bool(mine.any()):
+            rows = torch.nonzero(mine).reshape(-1).to(torch.int32)
+            sgt[rows.long()] = self.ops.pair_scores(qp, self.panel, rows, (gt[rows.long()] - self.lo).to(torch.int32))
+        if self.world > 1:
+            dist.all_reduce(sgt, group=self.group)                 # exactly one rank contributed a non-zero per query
+        ahead = torch.zeros(nq, dtype=torch.int32, device=dev)
+        if self.panel is not None:
+            s, i = self.ops.sim_topk(qp, self.panel, k, self.lo, gt, sgt, ahead)
+        else:
+            s = torch.full((nq, k), float("-inf"), dtype=torch.float32, device=dev)
+            i = torch.full((nq, k), -1, dtype=torch.int32, device=dev)
+        if self.world > 1:
+            dist.all_reduce(ahead, group=self.group)
+            ss = all_gather_rows(s.unsqueeze(0), self.group)
+            ii = all_gather_rows(i.unsqueeze(0), self.group)
+            s, i = self.ops.topk_merge(ss.permute(1, 0, 2).contiguous(), ii.permute(1, 0, 2).contiguous(), k)
+        return ahead.long() + 1, s, i

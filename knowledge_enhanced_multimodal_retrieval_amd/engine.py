@@ -193,7 +193,8 @@ def sim_topk(qp: Panel, gp: Panel, k: int, gallery_offset: int = 0,
              ahead: Optional[torch.Tensor] = None,
              bonus: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
              ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Fused scores + top-k (+ `ahead` counts when a ground truth is given). Returns (scores [nq,k], ids [nq,k])."""
+    """Fused scores + top-k (+ `ahead` counts when a ground truth is given). Returns (scores [nq,k], ids [nq,k]).
+    k == 0 = rank only (needs the ground truth; the returned tensors are empty)."""
     L = _lib.lib()
     if qp.kdim != gp.kdim:
         raise RuntimeError(f"sim_topk: panel kdim mismatch ({qp.kdim} vs {gp.kdim})")
@@ -205,7 +206,7 @@ def sim_topk(qp: Panel, gp: Panel, k: int, gallery_offset: int = 0,
         return top_s, top_i
     if ng == 0:
         return top_s.fill_(float("-inf")), top_i.fill_(-1)
-    ws = torch.empty(int(L.kemr_sim_workspace_bytes(nq, ng, k)), dtype=torch.uint8, device=dev)
+    ws = torch.empty(max(int(L.kemr_sim_workspace_bytes(nq, ng, k)), 256), dtype=torch.uint8, device=dev)
     if gt_idx is not None:
         if gt_score is None or ahead is None:
             raise RuntimeError("sim_topk: gt_idx needs gt_score and ahead")

@@ -1,0 +1,112 @@
+"""CPU, world_size = 2 over gloo: the collective plumbing of the sharded gallery (all-gather of queries, per-shard
+search with global ids, all-gather + merge of candidates, ground-truth score / `ahead` reductions).  The kernel calls
+are replaced by an oracle-backed stand-in (TEST ONLY: the product path always uses the HIP `engine` module)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleOps:
+    """numpy stand-in with the signatures of engine.build_panel / sim_topk / pair_scores / topk_merge."""
+
+    class P:
+        def __init__(self, mat):
+            self.mat, self.rows, self.kdim, self.device = mat, mat.shape[0], mat.shape[1], torch.device("cpu")
+
+    @staticmethod
+    def build_panel(parts, side, terms=3, part_scale=None, row_scale=None):
+        cols = []
+        for p, t in enumerate(parts):
+            x = t.double().numpy().copy()
+            if part_scale is not None:
+                x *= part_scale[p]
+            if row_scale is not None and row_scale[p] is not None:
+                x *= row_scale[p].double().numpy()[:, None]
+            cols.append(x)
+        return OracleOps.P(np.concatenate(cols, 1))
+
+    @staticmethod
+    def _order(S, ids):
+        return np.lexsort((ids, -S))
+
+    @staticmethod
+    def sim_topk(qp, gp, k, gallery_offset=0, gt_idx=None, gt_score=None, ahead=None, bonus=None):
+        S = qp.mat @ gp.mat.T
+        ids = np.arange(gp.rows) + gallery_offset
+        top_s = np.full((qp.rows, k), -np.inf, np.float32)
+        top_i = np.full((qp.rows, k), -1, np.int32)
+        for r in range(qp.rows):
+            o = OracleOps._order(S[r], ids)[:k]
+            top_s[r, :len(o)], top_i[r, :len(o)] = S[r, o], ids[o]
+            if gt_idx is not None:
+                g, sg = int(gt_idx[r]), float(gt_score[r])
+                before = (S[r].astype(np.float32) > np.float32(sg)) | ((S[r].astype(np.float32) == np.float32(sg)) & (ids < g))
+                ahead[r] += int((before & (ids != g)).sum())
+        return torch.from_numpy(top_s), torch.from_numpy(top_i)
+
+    @staticmethod
+    def pair_scores(qp, gp, q_rows, g_rows):
+        return torch.from_numpy(np.einsum("ij,ij->i", qp.mat[q_rows.numpy()], gp.mat[g_rows.numpy()]).astype(np.float32))
+
+    @staticmethod
+    def topk_merge(scores, idx, k):
+        nq = scores.shape[0]
+        s, i = scores.reshape(nq, -1).numpy(), idx.reshape(nq, -1).numpy()
+        out_s = np.full((nq, k), -np.inf, np.float32)
+        out_i = np.full((nq, k), -1, np.int32)
+        for r in range(nq):
+            ok = i[r] >= 0
+            o = np.lexsort((i[r][ok], -s[r][ok]))[:k]
+            out_s[r, :len(o)], out_i[r, :len(o)] = s[r][ok][o], i[r][ok][o]
+        return torch.from_numpy(out_s), torch.from_numpy(out_i)
+
+
+def _worker(rank, world, port, n, nq, d, k, q_out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from knowledge_enhanced_multimodal_retrieval_amd.dist import ShardedGallery, shard_bounds
+    from oracle import metrics_ref
+    img, q, t = metrics_ref.planted_embeddings(n, d, seed=3)
+    lo, hi = shard_bounds(n, world, rank)
+    gal = ShardedGallery([torch.from_numpy(img[lo:hi]), torch.from_numpy(t[lo:hi])], n, group=None, ops=OracleOps)
+    per = nq // world
+    ql = torch.from_numpy(q[rank * per:(rank + 1) * per])
+    gt_l = torch.arange(rank * per, (rank + 1) * per, dtype=torch.int32)
+    s, i = gal.search([ql, ql], weights=[0.3, 0.7], k=k)
+    ranks, s2, i2 = gal.ranks([ql, ql], gt_l, weights=[0.3, 0.7], k=k)
+    assert torch.equal(i, i2)
+    q_out.put((rank, s.numpy(), i.numpy(), ranks.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [101, 64])
+def test_sharded_search_world2(n):
+    from oracle import metrics_ref
+    world, nq, d, k = 2, 16, 32, 5
+    port = 29500 + (os.getpid() + n) % 2000
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, nq, d, k, q_out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q_out.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    img, q, t = metrics_ref.planted_embeddings(n, d, seed=3)
+    S = 0.3 * (q[:nq].astype(np.float64) @ img.astype(np.float64).T) + 0.7 * (q[:nq].astype(np.float64) @ t.astype(np.float64).T)
+    exp_s, exp_i = metrics_ref.topk(S, k)
+    exp_r = metrics_ref.ranks_by_count(S.astype(np.float32), np.arange(nq))
+    for rank, s, i, ranks in results:                       # every rank ends with the full, identical answer
+        assert np.array_equal(i, exp_i), rank
+        np.testing.assert_allclose(s, exp_s, atol=1e-6)
+        assert np.array_equal(ranks, exp_r)

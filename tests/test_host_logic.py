@@ -1,0 +1,228 @@
+"""CPU: host-side logic of the drop-in API (no kernel runs here; anything that needs the GPU must raise)."""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from knowledge_enhanced_multimodal_retrieval_amd import (clip_api, clip_model, config, datasets, ranking, retriever,
+                                                         sparql_fusion, tokenizer)
+from knowledge_enhanced_multimodal_retrieval_amd.clip_module import CLIP
+from oracle import clip_ref, fusion_ref
+
+NO_GPU = not torch.cuda.is_available()
+
+
+def test_arch_presets_and_flops():
+    a = config.get_arch("ViT-L/14")
+    assert (a.v_tokens, a.v_width, a.t_width, a.embed_dim) == (257, 1024, 768, 768)
+    assert a.image_flops() / 1e9 == pytest.approx(162.0, abs=0.1)
+    assert a.text_flops() / 1e9 == pytest.approx(13.30, abs=0.01)
+    b = config.get_arch("ViT-B/32")
+    assert b.image_flops() / 1e9 == pytest.approx(8.82, abs=0.01) and b.text_flops() / 1e9 == pytest.approx(5.96, abs=0.01)
+    with pytest.raises(RuntimeError):
+        config.get_arch("RN50")
+    for name in ("tiny", "tiny-long", "ViT-L/14", "ViT-B/32"):          # product presets == oracle presets
+        assert config.ARCHS[name].as_dict() == clip_ref.ARCHS[name]
+
+
+def test_module_state_dict_matches_openai_names_and_engine():
+    from knowledge_enhanced_multimodal_retrieval_amd import _lib
+    import ctypes as C
+    arch = config.ARCHS["tiny"]
+    m = CLIP(arch)
+    sd = clip_ref.random_state_dict(clip_ref.ARCHS["tiny"], seed=0)
+    assert set(m.state_dict()) == set(sd)
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    m.load_state_dict(sd, strict=True)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: v for k, v in sd.items() if k != "ln_final.bias"}, strict=True)
+    cfg = _lib.KemrCfg(**arch.as_dict())
+    h = C.c_void_p()
+    _lib.check(_lib.lib().kemr_model_create(C.byref(cfg), C.byref(h)))
+    names = {_lib.lib().kemr_model_tensor_name(h, i).decode() for i in range(_lib.lib().kemr_model_num_tensors(h))}
+    assert names == set(sd) - {"logit_scale"}
+    _lib.lib().kemr_model_destroy(h)
+    # attribute surface the reference's freeze helper walks (clip_model.py:193-216)
+    clip_model.freeze_clip_encoders(m)
+    trainable = {n for n, p in m.named_parameters() if p.requires_grad}
+    # the reference's rule is `'proj' in name` for the visual tower (so in_proj / out_proj / c_proj stay trainable too)
+    want = {"visual." + n for n, _ in m.visual.named_parameters() if "proj" in n} | \
+        {"text_projection", "ln_final.weight", "ln_final.bias", "logit_scale"}
+    assert trainable == want and "visual.proj" in trainable and "visual.conv1.weight" not in trainable
+    clip_model.unfreeze_clip_encoders(m)
+    assert clip_model.get_trainable_params(m) == sum(p.numel() for p in m.parameters())
+
+
+@pytest.mark.skipif(not NO_GPU, reason="checks the loud failure on a GPU-less machine")
+def test_no_cpu_fallback_anywhere():
+    m = CLIP(config.ARCHS["tiny"])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.encode_image(torch.zeros(1, 3, 32, 32))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.encode_text(torch.zeros(1, 16, dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ranking.ranks_and_topk([np.eye(4, 8, dtype=np.float32)], [np.eye(4, 8, dtype=np.float32)])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sparql_fusion.evaluate_retrieval(np.eye(4, dtype=np.float32))
+    from src.clip.eval.metrics import compute_retrieval_metrics
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        compute_retrieval_metrics(np.eye(4, 8, dtype=np.float32), np.eye(4, 8, dtype=np.float32))
+
+
+def test_checkpoint_round_trip(tmp_path):
+    m = CLIP(config.ARCHS["tiny"])
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    path = str(tmp_path / "ck.pt")
+    clip_model.save_checkpoint(m, opt, epoch=3, best_metric=41.5, best_epoch=2, save_path=path)
+    ck = torch.load(path, weights_only=True)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "best_metric", "best_epoch"}
+    m2 = CLIP(config.ARCHS["tiny"])
+    assert clip_model.load_checkpoint_for_resuming(path, m2, torch.optim.SGD(m2.parameters(), lr=0.1)) == (3, 41.5, 2)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert clip_api.read_state_dict(path).keys() == m.state_dict().keys()
+
+
+def test_tokenize_contract():
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        t = tokenizer.tokenize(["a bronze statue", "", "word " * 300], truncate=True)
+        assert t.shape == (3, 77) and t.dtype == torch.int32
+        assert (t[:, 0] == tokenizer.SOT).all()
+        assert t[1, 1] == tokenizer.EOT and (t[1, 2:] == 0).all()
+        assert t[2, 76] == tokenizer.EOT                                  # truncated: last position forced to EOT
+        assert (t.argmax(dim=1) == torch.tensor([4, 1, 76])).all()        # EOT is the row maximum (argmax pooling)
+        with pytest.raises(RuntimeError, match="too long"):
+            tokenizer.tokenize(["word " * 300])
+        assert torch.equal(tokenizer.tokenize("A  Bronze&amp;Statue"), tokenizer.tokenize(["a bronze&statue"]))
+    assert tokenizer.bytes_to_unicode()[ord("a")] == "a" and len(tokenizer.bytes_to_unicode()) == 256
+
+
+def test_bpe_tokenizer_with_a_small_merge_table(tmp_path):
+    import gzip
+    merges = ["#version: test"] + ["a b", "ab c</w>", "d e</w>"] + [f"x{i} y{i}" for i in range(49152 - 256 - 2 - 3)]
+    p = tmp_path / "bpe.txt.gz"
+    with gzip.open(p, "wt", encoding="utf-8") as f:
+        f.write("\n".join(merges))
+    tok = tokenizer.BPETokenizer(str(p))
+    assert len(tok.encoder) == 49408 and tok.encoder["<|endoftext|>"] == 49407
+    assert tok.bpe("abc") == "abc</w>" and tok.bpe("de") == "de</w>" and tok.bpe("ba") == "b a</w>"
+    assert tok.encode("abc de") == [tok.encoder["abc</w>"], tok.encoder["de</w>"]]
+
+
+def test_preprocess_matches_recipe():
+    from PIL import Image
+    from knowledge_enhanced_multimodal_retrieval_amd.preprocess import CLIP_MEAN, CLIP_STD, ClipPreprocess
+    rng = np.random.default_rng(0)
+    img = Image.fromarray(rng.integers(0, 255, (300, 500, 3), dtype=np.uint8))
+    x = ClipPreprocess(224)(img)
+    assert x.shape == (3, 224, 224) and x.dtype == torch.float32
+    ref = img.resize((373, 224), Image.BICUBIC).crop((74, 0, 298, 224))     # int(224*500/300)=373, round((373-224)/2)=74
+    r = (torch.from_numpy(np.asarray(ref).copy()).permute(2, 0, 1).float() / 255 - torch.tensor(CLIP_MEAN).view(3, 1, 1)) \
+        / torch.tensor(CLIP_STD).view(3, 1, 1)
+    assert torch.allclose(x, r, atol=1e-6)
+    assert ClipPreprocess(224)(Image.new("L", (224, 224), 128)).shape == (3, 224, 224)
+
+
+def test_dataset_contract():
+    class Row(dict):
+        pass
+    from PIL import Image
+    rows = [{"image": Image.new("L", (50, 40), 7), "query_text": "q " * 200, "target_text": "t", "uuid": "u0"},
+            {"image": None, "query_text": "q", "target_text": "t", "uuid": "u1"}]
+    ds = datasets.CLIPEvalDatasetHF(rows, preprocessor=lambda im: torch.ones(3, 224, 224))
+    im, q, t, u = ds[0]
+    assert len(q.split()) == 150 and u == "u0" and im.shape == (3, 224, 224)
+    im1, *_ = ds[1]
+    assert torch.equal(im1, torch.zeros(3, 224, 224))                    # decode failure -> zero image
+    batch = datasets.collate_fn_eval([ds[0], ds[1]])
+    assert batch[0].shape == (2, 3, 224, 224) and batch[1][1] == "q" and batch[3] == ["u0", "u1"]
+    syn = datasets.SyntheticRetrievalDataset(5, 32, seed=1)
+    a, b = syn[3], syn[3]
+    assert torch.equal(a[0], b[0]) and a[1:] == b[1:] and a[3] == "synthetic-000003" and a[0].shape == (3, 32, 32)
+
+
+def test_sparql_dense_api_and_csr_match_reference_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "sparql_fusion.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    S, uu, res = z["S"], meta["uuids"], meta["results"]
+    np.testing.assert_allclose(sparql_fusion.fuse_clip_and_text2sparql(S, res, uu, uu, "weighted", {"alpha": 0.7, "sparql_weight": 0.3}),
+                               z["weighted_a0.7"], atol=1e-7)
+    np.testing.assert_allclose(sparql_fusion.weighted_fusion(S, res, uu, uu, 0.6, 0.6), z["weighted_a0.6_w0.6"], atol=1e-7)
+    np.testing.assert_allclose(sparql_fusion.fuse_clip_and_text2sparql(S, res, uu, uu, "additive", {"delta": 0.5}),
+                               z["additive_d0.5"], atol=1e-7)
+    np.testing.assert_allclose(sparql_fusion.adaptive_additive_fusion(S, res, uu, uu), z["adaptive_d0.5"], atol=1e-7)
+    with pytest.raises(ValueError):
+        sparql_fusion.fuse_clip_and_text2sparql(S, res, uu, uu, "nope")
+    with pytest.raises(AssertionError):
+        sparql_fusion.weighted_fusion(S[:, :5], res, uu, uu)
+    scale, (ptr, col, val) = sparql_fusion.sparql_bonus(res, uu, uu, "weighted", {"alpha": 0.8, "sparql_weight": 0.2})
+    assert scale == pytest.approx(0.8) and ptr[0] == 0 and ptr[-1] == len(col) == len(val) and ptr.dtype == np.int32
+    for r in range(len(uu)):
+        seg = col[ptr[r]:ptr[r + 1]]
+        assert (np.diff(seg) > 0).all()                                   # ascending, de-duplicated within a row
+    dense = np.zeros_like(S)
+    dense[np.repeat(np.arange(len(uu)), np.diff(ptr)), col] = val
+    np.testing.assert_allclose(scale * S + dense, fusion_ref.weighted(S, res, uu, uu, 0.8, 0.2), atol=1e-7)
+
+
+def test_retrieval_engine_fuse_matches_golden(golden_dir):
+    with open(os.path.join(golden_dir, "engine_fuse.json")) as f:
+        g = json.load(f)
+
+    class FakeClip:
+        def retrieval(self, query, alpha=0.5):
+            assert alpha == 0.3
+            return list(g["clip_results"])
+
+    class FakeT2S:
+        def retrieval(self, query):
+            return list(g["sparql_results"])
+
+    from src.retrieval import RetrievalEngine
+    eng = RetrievalEngine(clip_retriever=FakeClip(), t2s_retriever=FakeT2S())
+    assert eng.retrieve_text("q", alpha=g["alpha"], beta=g["beta"], alpha_clip=0.3, threshold=-1) == g["expected"]
+    kept = eng.retrieve_text("q", alpha_clip=0.3, threshold=0.3)
+    assert kept == [e for e in g["expected"] if e["score"] >= 0.3]
+    assert eng.retrieve_text_noknowledge("q", alpha_clip=0.3, threshold=0.4) == \
+        [{"uuid": c["uuid"], "score": c["score"]} for c in g["clip_results"] if c["score"] >= 0.4]
+    assert eng._fuse_clip_sparql_linear([], ["x"]) == []
+    assert retriever.NoText2SPARQL().retrieval("x") == []
+
+
+def test_text2sparql_results_loader(tmp_path, monkeypatch):
+    from knowledge_enhanced_multimodal_retrieval_amd import evaluators
+    assert evaluators.load_text2sparql_results(str(tmp_path / "missing")) == {}
+    d = tmp_path / "res"
+    d.mkdir()
+    (d / "abc.txt").write_text("http://x/y/u1\nu2\n")
+    assert evaluators.load_text2sparql_results(str(d)) == {"abc": ["http://x/y/u1", "u2"]}
+
+
+def test_cli_flags_match_reference_scripts():
+    """scripts/baselines/*.sh and scripts/fusion/eval.sh pass these flags (incl. --splits_file, which the reference's
+    evaluator_baseline does not declare)."""
+    import argparse
+    from knowledge_enhanced_multimodal_retrieval_amd import evaluators
+    p = argparse.ArgumentParser()
+    evaluators._common_args(p, baseline=True)
+    a = p.parse_args("--model_name ViT-L/14 --checkpoint c.pt --images_dir i --texts_dir t --split val --splits_file s.json "
+                     "--batch_size 64 --device cuda --output_file o.json --t2i_weight 0.5 --t2t_weight 0.5".split())
+    assert a.split == "val" and a.t2i_weight == 0.5 and a.synthetic == 0
+    p2 = argparse.ArgumentParser()
+    evaluators._common_args(p2, baseline=False)
+    a2 = p2.parse_args("--model_name ViT-B/32 --images_dir i --texts_dir t --split test --splits_file s --batch_size 64 "
+                       "--device cuda --output_file o.json --seed 42".split())
+    assert a2.seed == 42 and a2.tasks == ["T2I", "I2T", "T2T"]
+
+
+def test_shard_bounds():
+    from knowledge_enhanced_multimodal_retrieval_amd.dist import shard_bounds
+    assert [shard_bounds(43000, 8, r) for r in range(8)][0] == (0, 5375)
+    cover = [shard_bounds(10, 4, r) for r in range(4)]
+    assert cover == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert shard_bounds(2, 4, 3) == (2, 2)
