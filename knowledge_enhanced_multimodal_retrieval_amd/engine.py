@@ -215,6 +215,8 @@ def sim_topk(qp: Panel, gp: Panel, k: int, gallery_offset: int = 0,
         if ahead.dtype != torch.int32 or not ahead.is_contiguous() or ahead.device != dev:
             raise RuntimeError("sim_topk: ahead must be a contiguous int32 tensor on the panel's device")
     b_ptr = b_col = b_val = None
+    if bonus is not None and len(bonus[1]) == 0:      # no hit at all: same as no bonus (empty tensors have no address)
+        bonus = None
     if bonus is not None:
         b_ptr, b_col, b_val = (torch.as_tensor(bonus[0]).to(device=dev, dtype=torch.int32).contiguous(),
                                torch.as_tensor(bonus[1]).to(device=dev, dtype=torch.int32).contiguous(),
