@@ -53,6 +53,7 @@ SIGNATURES = {
     "kemr_linear_head": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _f, _i, _vp, _vp]),
     "kemr_profile_begin": (_i, [_i]),
     "kemr_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i64), _i]),
+    "kemr_set_gemm_variant": (_i, [_i]),
     "kemr_op_gemm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "kemr_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "kemr_op_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -370,6 +370,12 @@ extern "C" int kemr_encode_text(kemr_model* m, const int32_t* ids_dev, int batch
     return KEMR_OK;
 }
 
+extern "C" int kemr_set_gemm_variant(int variant) {
+    if (variant < 0 || variant > 2) KEMR_FAIL(KEMR_ERR_INVALID, "set_gemm_variant: 0 auto, 1 = 128x128 tiles, 2 = 256x256 tiles");
+    g_gemm_variant = variant;
+    return KEMR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ event profiler
 extern "C" int kemr_profile_begin(int max_launches) {
     if (max_launches <= 0 || max_launches > (1 << 20)) KEMR_FAIL(KEMR_ERR_INVALID, "profile_begin: bad max_launches");

@@ -77,7 +77,9 @@ struct GemmParams {
     int lda, ldw, ldc;
     int patches;         // EPI_PATCH_F32: patches per image (row remap m -> m + m / patches + 1)
 };
-int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
+int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);      // picks the tile variant
+int launch_gemm256(const GemmParams& p, int epi, hipStream_t stream);   // gemm256.hip: 256x256x64, 8 waves, counted vmcnt
+extern int g_gemm_variant;   // 0 auto, 1 force 128x128 (gemm.hip), 2 force 256x256 where the shape allows
 
 // ---- other launchers --------------------------------------------------------------------------
 int launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int rows, int width,

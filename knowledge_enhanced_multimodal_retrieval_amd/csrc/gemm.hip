@@ -166,12 +166,18 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
     return KEMR_OK;
 }
 
+int g_gemm_variant = 0;
+
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     if (p.M <= 0) return KEMR_OK;
     if (p.N % 128 != 0 || p.K % BK != 0 || p.K <= 0)
         KEMR_FAIL(KEMR_ERR_INVALID, "gemm: need N %% 128 == 0 and K %% 64 == 0 (got M=%d N=%d K=%d)", p.M, p.N, p.K);
     if ((p.lda % 8) || (p.ldw % 8) || (p.ldc % 4))
         KEMR_FAIL(KEMR_ERR_INVALID, "gemm: leading dimensions must keep 16-byte alignment");
+    // 256x256 tiles (one workgroup per CU, deep LDS-DMA pipeline) once there is at least ~half a wave of them
+    const bool can256 = p.N % 256 == 0 && p.K >= 128;
+    const long tiles256 = (long)((p.M + 255) / 256) * (p.N / 256);
+    if (can256 && (g_gemm_variant == 2 || (g_gemm_variant == 0 && tiles256 >= 128))) return launch_gemm256(p, epi, stream);
     switch (epi) {
         case EPI_BIAS_BF16:       return launch_cfg<128, 128, 2, 2, EPI_BIAS_BF16>(p, stream);
         case EPI_BIAS_QGELU_BF16: return launch_cfg<128, 128, 2, 2, EPI_BIAS_QGELU_BF16>(p, stream);

@@ -290,6 +290,11 @@ def rank_dense(scores: torch.Tensor, gt_idx: Optional[torch.Tensor] = None, k: i
 
 
 # ---------------------------------------------------------------------- per-kernel hooks used by tests
+def set_gemm_variant(variant: int) -> None:
+    """0 = automatic tile choice, 1 = force 128x128, 2 = force 256x256 where N % 256 == 0 (tests / A-B benchmarks)."""
+    _lib.check(_lib.lib().kemr_set_gemm_variant(variant), "set_gemm_variant")
+
+
 def op_gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], m: int, epilogue: int,
             c: Optional[torch.Tensor] = None) -> torch.Tensor:
     """a: bf16 [m_alloc, k] (m_alloc multiple of 256), w: bf16 [n, k]; returns C (bf16 [m_alloc, n] or the fp32 residual)."""

@@ -15,7 +15,16 @@ def _bf16_round(x):
 
 @pytest.mark.parametrize("m,n,k", [(257, 256, 256), (300, 768, 256), (1000, 1024, 1024), (514, 256, 1024), (63 * 257, 1024, 1024)])
 @pytest.mark.parametrize("epi", [_lib.EPI_BIAS_BF16, _lib.EPI_BIAS_QGELU_BF16, _lib.EPI_BIAS_RESID_F32])
-def test_gemm_epilogues(device, m, n, k, epi):
+@pytest.mark.parametrize("variant", [1, 2])
+def test_gemm_epilogues(device, m, n, k, epi, variant):
+    engine.set_gemm_variant(variant)      # 1: 128x128 tiles, 2: 256x256 tiles (every N here is a multiple of 256)
+    try:
+        _gemm_epilogue_case(device, m, n, k, epi)
+    finally:
+        engine.set_gemm_variant(0)
+
+
+def _gemm_epilogue_case(device, m, n, k, epi):
     g = torch.Generator().manual_seed(m * 7 + n + k + epi)
     m_alloc = (m + 255) // 256 * 256
     a = torch.randn(m_alloc, k, generator=g)
@@ -42,15 +51,38 @@ def test_gemm_epilogues(device, m, n, k, epi):
         assert float(got[m:].abs().max()) == 0.0 if m < m_alloc else True
 
 
-def test_gemm_identity_asymmetric(device):
+@pytest.mark.parametrize("variant", [1, 2])
+def test_gemm_identity_asymmetric(device, variant):
     """A = I against an asymmetric W catches transposed / permuted fragment maps (cdna guide section 3)."""
-    k = n = 256
-    m_alloc = 256
+    k = n = 512
+    m_alloc = 512
     a = torch.eye(m_alloc, k)
     w = (torch.arange(n * k, dtype=torch.float32).reshape(n, k) % 251) - 125.0        # exact in bf16
-    out = engine.op_gemm(a.to(torch.bfloat16).to(device), w.to(torch.bfloat16).to(device), None, 256, _lib.EPI_BIAS_BF16)
+    engine.set_gemm_variant(variant)
+    try:
+        out = engine.op_gemm(a.to(torch.bfloat16).to(device), w.to(torch.bfloat16).to(device), None, 512, _lib.EPI_BIAS_BF16)
+    finally:
+        engine.set_gemm_variant(0)
     torch.cuda.synchronize()
     assert torch.equal(out.float().cpu(), w.T.contiguous().to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("k", [64, 128, 192, 4096])
+def test_gemm256_short_and_long_k(device, k):
+    """Pipeline prologue / tail of the 256x256 kernel: 1, 2, 3 and 64 K-tiles (K = 64 falls back to 128x128)."""
+    g = torch.Generator().manual_seed(k)
+    m, n = 700, 512
+    a = torch.randn(768, k, generator=g).to(torch.bfloat16)
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(torch.bfloat16)
+    ref = a.float()[:m] @ w.float().T
+    engine.set_gemm_variant(2)
+    try:
+        out = engine.op_gemm(a.to(device), w.to(device), None, m, _lib.EPI_BIAS_RESID_F32,
+                             c=torch.zeros(768, n, device=device))
+    finally:
+        engine.set_gemm_variant(0)
+    torch.cuda.synchronize()
+    assert float((out.cpu()[:m] - ref).abs().max()) < 2e-4 * (1 + float(ref.abs().max()))
 
 
 def test_gemm_rejects_bad_shapes(device):
