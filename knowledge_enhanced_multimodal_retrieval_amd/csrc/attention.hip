@@ -22,10 +22,11 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
 }
 
 template <int NT32, bool CAUSAL>   // keys padded to NT32 * 32
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                        int T, int width) {
+__global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                           int T, int width) {
     constexpr int TP = NT32 * 32;
     constexpr int NT16 = NT32 * 2;
+    constexpr int NCH = (TP * 8 + 255) / 256;          // 16-byte chunks of K (and of V) per thread
     constexpr float LOG2E = 1.4426950408889634f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;
@@ -36,57 +37,86 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ld = 3 * width;
     const bf16_t* base = qkv + (size_t)b * T * ld + h * 64;
+    const int lrow = lane & 15, lq = lane >> 4;
+    const int nqt = (T + 15) >> 4;
 
-    for (int idx = tid; idx < TP * 8; idx += 256) {
-        const int row = idx >> 3, c = idx & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (row < T) {
-            kv = *(const uint4*)(base + (size_t)row * ld + width + c * 8);
-            vv = *(const uint4*)(base + (size_t)row * ld + 2 * width + c * 8);
+    // first query tile of this wave: issue its loads before the K/V staging so that their latency overlaps it
+    bf16x8 qn[2];
+    {
+        const int q0 = wid * 16 + lrow;
+        const int qc = q0 < T ? q0 : T - 1;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) qn[kk] = *(const bf16x8*)(base + (size_t)qc * ld + kk * 32 + lq * 8);
+    }
+    // stage K then V: all global loads of a matrix in flight together, then the swizzled LDS writes
+#pragma unroll
+    for (int mat = 0; mat < 2; ++mat) {
+        uint4 v[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx >> 3, c = idx & 7;
+            v[i] = make_uint4(0, 0, 0, 0);
+            if (idx < TP * 8 && row < T) v[i] = *(const uint4*)(base + (size_t)row * ld + (mat + 1) * width + c * 8);
         }
-        *(uint4*)(sK + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kv;
-        *(uint4*)(sV + row * 128 + ((c ^ (((row >> 1) & 3) << 1)) << 4)) = vv;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx >> 3, c = idx & 7;
+            if (idx < TP * 8) {
+                if (mat == 0) *(uint4*)(sK + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v[i];
+                else          *(uint4*)(sV + row * 128 + ((c ^ (((row >> 1) & 3) << 1)) << 4)) = v[i];
+            }
+        }
     }
     __syncthreads();
 
-    const int lrow = lane & 15, lq = lane >> 4;
-    const int nqt = (T + 15) >> 4;
     for (int qt = wid; qt < nqt; qt += 4) {            // wave-uniform trip count: EXEC stays full for the tr reads
         const int q = qt * 16 + lrow;
-        const int qc = q < T ? q : T - 1;
-        bf16x8 qf[2];
+        bf16x8 qf[2] = {qn[0], qn[1]};
+        if (qt + 4 < nqt) {                            // prefetch the next query tile of this wave
+            const int q2 = q + 64;
+            const int qc = q2 < T ? q2 : T - 1;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const bf16x8*)(base + (size_t)qc * ld + kk * 32 + lq * 8);
+            for (int kk = 0; kk < 2; ++kk) qn[kk] = *(const bf16x8*)(base + (size_t)qc * ld + kk * 32 + lq * 8);
+        }
 
         f32x4 s[NT16];
 #pragma unroll
         for (int t = 0; t < NT16; ++t) {
             s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t * 16 < T) {                          // tiles made only of pad keys are skipped (uniform)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + lrow) * 128 + (((kk * 4 + lq) ^ (lrow >> 1)) << 4));
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + lrow) * 128 + (((kk * 4 + lq) ^ (lrow >> 1)) << 4));
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
+                }
             }
         }
         // s[t][r] = S[query lrow][key t*16 + lq*4 + r]
         float mx = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < NT16; ++t)
+        for (int t = 0; t < NT16; ++t) {
+            const bool partial = (t + 1) * 16 > T || CAUSAL;   // only the boundary tiles (or causal) need a mask
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = t * 16 + lq * 4 + r;
-                const bool ok = key < T && (!CAUSAL || key <= q);
-                s[t][r] = ok ? s[t][r] : -INFINITY;
+                if (partial) {
+                    const int key = t * 16 + lq * 4 + r;
+                    const bool ok = key < T && (!CAUSAL || key <= q);
+                    s[t][r] = ok ? s[t][r] : -INFINITY;
+                }
                 mx = fmaxf(mx, s[t][r]);
             }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mxl = mx * LOG2E;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < NT16; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s[t][r] = exp2f((s[t][r] - mx) * LOG2E);
+                s[t][r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], LOG2E, -mxl));   // exp(s - max); masked keys -> 0
                 sum += s[t][r];
             }
         sum += __shfl_xor(sum, 16);
@@ -97,6 +127,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < NT32; ++u) {
+            if (u * 32 >= T) continue;                 // all-pad key block (uniform)
             union { bf16x8 v; uint32_t w[4]; } pf;
             pf.w[0] = pack_bf16x2(s[2 * u][0], s[2 * u][1]);
             pf.w[1] = pack_bf16x2(s[2 * u][2], s[2 * u][3]);

@@ -101,25 +101,29 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ x, const int32_t* __restrict__ ids,
-                                                   int tokens, int width, const float* __restrict__ gamma,
-                                                   const float* __restrict__ beta, const float* __restrict__ proj,
-                                                   int d, int normalize, float* __restrict__ out) {
+// Pooling tail, part 1: pooled row -> LayerNorm -> 64 output columns of  y @ proj  per workgroup.
+// grid (ceil(d / 64), batch): every workgroup re-normalises its row (width <= 1280 floats, trivial) so that no
+// intermediate buffer is needed; wave w owns 16 columns, lane (g = lane >> 2, jq = lane & 3) accumulates columns
+// 4*jq..4*jq+3 over the rows i = g (mod 16) with 16-byte loads of the fp32 projection, then 4 shuffle steps.
+__global__ __launch_bounds__(256) void tail_proj_kernel(const float* __restrict__ x, const int32_t* __restrict__ ids,
+                                                        int tokens, int width, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ proj,
+                                                        int d, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* y = (float*)smem;          // [width] normalised row
     float* red = y + width;           // [4]
     int* pool = (int*)(red + 4);      // [1]
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
     if (tid < 64) {
         int best_t = 0;
         if (ids) {                    // first position of the row maximum (torch.argmax semantics)
             int best_v = INT_MIN;
+            best_t = INT_MAX;
             for (int t = tid; t < tokens; t += 64) {
                 const int v = ids[(size_t)b * tokens + t];
                 if (v > best_v) { best_v = v; best_t = t; }
             }
-            if (best_v == INT_MIN) best_t = INT_MAX;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 const int ov = __shfl_xor(best_v, o), ot = __shfl_xor(best_t, o);
@@ -140,38 +144,51 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ x, 
     for (int i = tid; i < width; i += 256) y[i] = (xr[i] - mean) * rstd * gamma[i] + beta[i];
     __syncthreads();
 
-    // out[j] = sum_i y[i] * proj[i][j]; threads walk j (coalesced proj reads), up to 4 outputs per thread
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < width; ++i) {
-        const float yi = y[i];
-        const float* pr = proj + (size_t)i * d;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int j = tid + e * 256;
-            if (j < d) acc[e] = fmaf(yi, pr[j], acc[e]);
+    const int j = blockIdx.x * 64 + wid * 16 + (lane & 3) * 4;     // first of this lane's 4 columns
+    const int g = lane >> 2;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < d) {                       // d % 4 == 0 (checked by the launcher)
+#pragma unroll 8
+        for (int i = g; i < width; i += 16) {
+            const float yi = y[i];
+            const float4 p = *(const float4*)(proj + (size_t)i * d + j);
+            acc.x = fmaf(yi, p.x, acc.x); acc.y = fmaf(yi, p.y, acc.y);
+            acc.z = fmaf(yi, p.z, acc.z); acc.w = fmaf(yi, p.w, acc.w);
         }
     }
-    float sq = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) sq += acc[e] * acc[e];
-    const float nrm = sqrtf(block_sum(sq, red));
-    const float scale = normalize ? 1.0f / nrm : 1.0f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int j = tid + e * 256;
-        if (j < d) out[(size_t)b * d + j] = acc[e] * scale;
+    for (int o = 4; o < 64; o <<= 1) {
+        acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o);
+        acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
     }
+    if (g == 0 && j < d) *(float4*)(out + (size_t)b * d + j) = acc;
+}
+
+// Pooling tail, part 2: x / ||x||_2 per row, in place (one wave per row; no eps, like the reference's `x / x.norm()`).
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x, int rows, int d) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* r = x + (size_t)row * d;
+    float s = 0.f;
+    for (int i = lane; i < d; i += 64) s += r[i] * r[i];
+    const float inv = 1.0f / sqrtf(wave_sum(s));
+    for (int i = lane; i < d; i += 64) r[i] *= inv;
 }
 
 int launch_tail(const float* x, const int32_t* ids, int batch, int tokens, int width, const float* gamma,
                 const float* beta, const float* proj, int d, int normalize, float* out, hipStream_t stream) {
     if (batch <= 0) return KEMR_OK;
-    if (d > 1024) KEMR_FAIL(KEMR_ERR_INVALID, "tail: embed_dim %d > 1024", d);
+    if (d % 4 != 0 || d <= 0) KEMR_FAIL(KEMR_ERR_INVALID, "tail: embed_dim %d must be a positive multiple of 4", d);
+    if (batch > 65535) KEMR_FAIL(KEMR_ERR_INVALID, "tail: batch %d > 65535", batch);
     const size_t smem = (size_t)width * 4 + 32;
     ProfScope prof(PROF_OTHER, stream);
-    hipLaunchKernelGGL(tail_kernel, dim3(batch), dim3(256), smem, stream, x, ids, tokens, width, gamma, beta, proj, d,
-                       normalize, out);
-    KEMR_CHECK_LAUNCH("tail_kernel");
+    hipLaunchKernelGGL(tail_proj_kernel, dim3((d + 63) / 64, batch), dim3(256), smem, stream, x, ids, tokens, width, gamma,
+                       beta, proj, d, out);
+    KEMR_CHECK_LAUNCH("tail_proj_kernel");
+    if (normalize) {
+        hipLaunchKernelGGL(l2norm_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, stream, out, batch, d);
+        KEMR_CHECK_LAUNCH("l2norm_rows_kernel");
+    }
     return KEMR_OK;
 }
 
