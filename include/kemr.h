@@ -189,8 +189,8 @@ typedef enum kemr_epilogue {
     KEMR_EPI_BIAS_RESID_F32 = 2    /* X_f32 += A.W^T + bias   (in place on the residual)      */
 } kemr_epilogue;
 /* A bf16 [m_alloc, k] (m_alloc = m rounded up to 256 rows, readable), W bf16 [n, k], bias fp32 [n] */
-/* tile variant used by every GEMM launch: 0 = automatic (default), 1 = 128x128x64 / 4 waves, 2 = 256x256x64 / 8 waves
- * wherever N % 256 == 0 (A/B benchmarking and tests; process-wide) */
+/* tile variant used by every GEMM launch: 0 = automatic (default), 1 = 128x128x64 / 4 waves, 2 = 256x256x64 / 8 waves in
+ * lockstep, 3 = 256x256x64 / 8 waves with staggered halves (2 and 3 wherever N % 256 == 0); A/B benchmarking and tests */
 int kemr_set_gemm_variant(int variant);
 int kemr_op_gemm(const void* a_dev, const void* w_dev, const float* bias_dev, void* c_dev,
                  int m, int n, int k, int epilogue, void* stream);

@@ -371,7 +371,7 @@ extern "C" int kemr_encode_text(kemr_model* m, const int32_t* ids_dev, int batch
 }
 
 extern "C" int kemr_set_gemm_variant(int variant) {
-    if (variant < 0 || variant > 2) KEMR_FAIL(KEMR_ERR_INVALID, "set_gemm_variant: 0 auto, 1 = 128x128 tiles, 2 = 256x256 tiles");
+    if (variant < 0 || variant > 3) KEMR_FAIL(KEMR_ERR_INVALID, "set_gemm_variant: 0 auto, 1 = 128x128, 2 = 256x256 lockstep, 3 = 256x256 staggered");
     g_gemm_variant = variant;
     return KEMR_OK;
 }

@@ -15,7 +15,7 @@ def _bf16_round(x):
 
 @pytest.mark.parametrize("m,n,k", [(257, 256, 256), (300, 768, 256), (1000, 1024, 1024), (514, 256, 1024), (63 * 257, 1024, 1024)])
 @pytest.mark.parametrize("epi", [_lib.EPI_BIAS_BF16, _lib.EPI_BIAS_QGELU_BF16, _lib.EPI_BIAS_RESID_F32])
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_gemm_epilogues(device, m, n, k, epi, variant):
     engine.set_gemm_variant(variant)      # 1: 128x128 tiles, 2: 256x256 tiles (every N here is a multiple of 256)
     try:
@@ -51,7 +51,7 @@ def _gemm_epilogue_case(device, m, n, k, epi):
         assert float(got[m:].abs().max()) == 0.0 if m < m_alloc else True
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_gemm_identity_asymmetric(device, variant):
     """A = I against an asymmetric W catches transposed / permuted fragment maps (cdna guide section 3)."""
     k = n = 512
@@ -67,15 +67,16 @@ def test_gemm_identity_asymmetric(device, variant):
     assert torch.equal(out.float().cpu(), w.T.contiguous().to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("variant", [2, 3])
 @pytest.mark.parametrize("k", [64, 128, 192, 4096])
-def test_gemm256_short_and_long_k(device, k):
+def test_gemm256_short_and_long_k(device, k, variant):
     """Pipeline prologue / tail of the 256x256 kernel: 1, 2, 3 and 64 K-tiles (K = 64 falls back to 128x128)."""
     g = torch.Generator().manual_seed(k)
     m, n = 700, 512
     a = torch.randn(768, k, generator=g).to(torch.bfloat16)
     w = (torch.randn(n, k, generator=g) * k ** -0.5).to(torch.bfloat16)
     ref = a.float()[:m] @ w.float().T
-    engine.set_gemm_variant(2)
+    engine.set_gemm_variant(variant)
     try:
         out = engine.op_gemm(a.to(device), w.to(device), None, m, _lib.EPI_BIAS_RESID_F32,
                              c=torch.zeros(768, n, device=device))
