@@ -188,9 +188,11 @@ typedef enum kemr_epilogue {
     KEMR_EPI_BIAS_QGELU_BF16 = 1,  /* C_bf16 = quickgelu(A.W^T + bias)                       */
     KEMR_EPI_BIAS_RESID_F32 = 2    /* X_f32 += A.W^T + bias   (in place on the residual)      */
 } kemr_epilogue;
-/* A bf16 [m_alloc, k] (m_alloc = m rounded up to 256 rows, readable), W bf16 [n, k], bias fp32 [n] */
+/* A bf16 [m_alloc, k] and C [m_alloc, n] with m_alloc = m rounded up to 256 rows (pad rows of A are read; pad rows of C
+ * may be written by the bf16 epilogues), W bf16 [n, k], bias fp32 [n] */
 /* tile variant used by every GEMM launch: 0 = automatic (default), 1 = 128x128x64 / 4 waves, 2 = 256x256x64 / 8 waves in
- * lockstep, 3 = 256x256x64 / 8 waves with staggered halves (2 and 3 wherever N % 256 == 0); A/B benchmarking and tests */
+ * lockstep, 3 = 256x256x64 / 8 waves with staggered halves, 4 = persistent 256x256 with asynchronous epilogue (bf16
+ * epilogues; 2-4 wherever N % 256 == 0); A/B benchmarking and tests */
 int kemr_set_gemm_variant(int variant);
 int kemr_op_gemm(const void* a_dev, const void* w_dev, const float* bias_dev, void* c_dev,
                  int m, int n, int k, int epilogue, void* stream);

@@ -309,6 +309,7 @@ int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, hipSt
         KEMR_TRY(launch_layernorm(w.x, L.ln1_g, L.ln1_b, w.h, M, W, KEMR_BF16, s));
         GemmParams g{};
         g.M = M;
+        g.c_rows_padded = 1;       // every workspace buffer has ceil256(M) rows
         g.A = w.h; g.lda = W; g.W = L.wqkv; g.ldw = W; g.bias = L.bqkv; g.C = w.big; g.ldc = 3 * W; g.N = 3 * W; g.K = W;
         KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
         KEMR_TRY(launch_attention(w.big, w.h, batch, t.tokens, W, causal, s));
@@ -371,8 +372,10 @@ extern "C" int kemr_encode_text(kemr_model* m, const int32_t* ids_dev, int batch
 }
 
 extern "C" int kemr_set_gemm_variant(int variant) {
-    if (variant < 0 || variant > 3) KEMR_FAIL(KEMR_ERR_INVALID, "set_gemm_variant: 0 auto, 1 = 128x128, 2 = 256x256 lockstep, 3 = 256x256 staggered");
-    g_gemm_variant = variant;
+    g_gemm_dbg = (variant >> 8) & 0xff;   // bits 8..15: timing-experiment flags (tools/ only)
+    variant &= 0xff;
+    if (variant < 0 || variant > 4) KEMR_FAIL(KEMR_ERR_INVALID, "set_gemm_variant: 0 auto, 1 = 128x128, 2 = 256x256 lockstep, 3 = 256x256 staggered, 4 = persistent");
+    g_gemm_variant = variant & 0xff;
     return KEMR_OK;
 }
 
@@ -414,6 +417,7 @@ extern "C" int kemr_op_gemm(const void* a_dev, const void* w_dev, const float* b
     GemmParams g{};
     g.A = (const bf16_t*)a_dev; g.lda = k; g.W = (const bf16_t*)w_dev; g.ldw = k; g.bias = bias_dev; g.C = c_dev; g.ldc = n;
     g.M = m; g.N = n; g.K = k;
+    g.c_rows_padded = 1;           // documented requirement of this entry point: C (like A) has ceil256(m) rows
     return launch_gemm(g, epilogue, (hipStream_t)stream);
 }
 

@@ -76,10 +76,14 @@ struct GemmParams {
     int M, N, K;         // M = valid rows (stores are guarded), N % 128 == 0, K % 64 == 0
     int lda, ldw, ldc;
     int patches;         // EPI_PATCH_F32: patches per image (row remap m -> m + m / patches + 1)
+    int dbg;             // timing experiments only (tools/): bit 0 = skip the epilogue stores
+    int c_rows_padded;   // C has ceil256(M) writable rows (lets the persistent kernel store without row masks)
 };
+extern int g_gemm_dbg;
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);      // picks the tile variant
 int launch_gemm256(const GemmParams& p, int epi, hipStream_t stream);   // gemm256.hip: 256x256x64, 8 waves, counted vmcnt
-extern int g_gemm_variant;   // 0 auto, 1 force 128x128 (gemm.hip), 2 force 256x256 where the shape allows
+int launch_gemm256p(const GemmParams& p, int epi, hipStream_t stream);  // gemm256p.hip: persistent, async epilogue (bf16-store epilogues)
+extern int g_gemm_variant;   // 0 auto, 1 = 128x128 (gemm.hip), 2 / 3 = 256x256 lockstep / staggered, 4 = persistent 256x256 (bf16 epilogues)
 
 // ---- other launchers --------------------------------------------------------------------------
 int launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int rows, int width,

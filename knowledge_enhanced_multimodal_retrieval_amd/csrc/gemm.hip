@@ -167,6 +167,7 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
 }
 
 int g_gemm_variant = 0;
+int g_gemm_dbg = 0;
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     if (p.M <= 0) return KEMR_OK;
@@ -177,6 +178,9 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     // 256x256 tiles (one workgroup per CU, deep LDS-DMA pipeline) once there is at least ~half a wave of them
     const bool can256 = p.N % 256 == 0 && p.K >= 128;
     const long tiles256 = (long)((p.M + 255) / 256) * (p.N / 256);
+    const bool bf16_epi = epi == EPI_BIAS_BF16 || epi == EPI_BIAS_QGELU_BF16;
+    if (can256 && bf16_epi && p.c_rows_padded && (g_gemm_variant == 4 || (g_gemm_variant == 0 && tiles256 >= 128)))
+        return launch_gemm256p(p, epi, stream);
     if (can256 && (g_gemm_variant >= 2 || (g_gemm_variant == 0 && tiles256 >= 128))) return launch_gemm256(p, epi, stream);
     switch (epi) {
         case EPI_BIAS_BF16:       return launch_cfg<128, 128, 2, 2, EPI_BIAS_BF16>(p, stream);

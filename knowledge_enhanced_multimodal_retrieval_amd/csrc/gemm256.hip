@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_nt_kernel(const GemmParam
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         const int m = row0 + wr * 128 + mi * 16 + lrow;
-        if (m >= p.M) continue;
+        if (m >= p.M || (p.dbg & 1)) continue;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int n = col0 + wc * 64 + ni * 16 + lq * 4;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_nt_kernel(const GemmPara
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         const int m = row0 + wr * 128 + mi * 16 + lrow;
-        if (m >= p.M) continue;
+        if (m >= p.M || (p.dbg & 1)) continue;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int n = col0 + wc * 64 + ni * 16 + lq * 4;
@@ -390,7 +390,7 @@ static int launch256(const GemmParams& p, hipStream_t stream) {
     const int tiles = ((p.M + 255) / 256) * (p.N / 256);
     ProfScope prof(PROF_GEMM, stream);
     if (g_gemm_variant == 3) hipLaunchKernelGGL(kern_stag, dim3(tiles), dim3(512), smem, stream, p);
-    else hipLaunchKernelGGL(kern_lock, dim3(tiles), dim3(512), smem, stream, p);
+    else { GemmParams q = p; q.dbg = g_gemm_dbg; hipLaunchKernelGGL(kern_lock, dim3(tiles), dim3(512), smem, stream, q); }
     KEMR_CHECK_LAUNCH("gemm256_bf16_nt_kernel");
     return KEMR_OK;
 }

@@ -1,0 +1,286 @@
+// Persistent bf16 GEMM for the bf16-output epilogues (bias, bias + QuickGELU): one 512-thread workgroup per CU walks
+// 256 x 256 output tiles; the epilogue of tile i overlaps the first K-tile loads of tile i+1 and its stores drain
+// behind the next tile's main loop.  Measured motivation (tools/bench_gemm_dbg.py): with the stores removed the
+// 256x256 kernels run the K = 1024 encoder shapes at ~1.34 PFLOP/s, with them at 0.57-0.91 -- the un-overlapped,
+// 8-byte-per-lane store tail was 30-58 % of the time.
+//
+// K loop: the staggered schedule of gemm256.hip (two barriers per phase, wr == 1 half one interval behind, MFMAs pinned
+// as volatile asm, counted vmcnt).  LDS: 128 KiB K-tile double buffer + 16 KiB epilogue area (2 KiB private per wave) + 2 x 1 KiB bias.
+//
+// Tile hand-over, in issue order per lane (vmcnt counts loads, LDS-DMA and stores together, in order):
+//   [wave 0: 1 LDS-DMA of the next tile's 256 bias floats] [10 LDS-DMA: A0,A1,B0,B1 of K-tile 0 and B0 of K-tile 1 of
+//   the NEXT tile] [16 stores of THIS tile]
+// No register-destination load exists in the kernel, so hipcc inserts no vmcnt wait of its own; the next tile enters its
+// K loop behind `s_waitcnt vmcnt(18)` = everything up to B1(0) landed, B0(1) and the 16 stores still in flight.
+// Every lane issues exactly 16 stores per tile (rows beyond M are NOT masked: C must have ceil256(M) rows), so the
+// count is exact.  The epilogue goes through the wave's private LDS area so that each store instruction writes
+// 8 full 128-byte lines (acc -> +bias -> act -> bf16 -> ds_write_b64, chunk-XOR swizzled -> ds_read_b128 -> 16 B / lane).
+#include "common.h"
+
+namespace kemr {
+
+namespace {
+
+constexpr int PBUF = 65536;      // bytes per K-tile buffer
+constexpr int PHALF = 16384;     // bytes per half-tile
+constexpr int PEPI = 131072;     // offset of the epilogue area (8 waves x 2 KiB)
+constexpr int PBIAS = PEPI + 16384;   // 2 x 1 KiB: fp32 bias of the current / next tile's 256 columns
+constexpr int PSMEM = PBIAS + 2048;
+
+__device__ __forceinline__ void glds16p(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Epilogue LDS traffic as inline asm: hipcc (SIInsertWaitcnts) guards every LDS access that carries a memory operand
+// with `s_waitcnt vmcnt(0)` while an LDS-DMA is outstanding, which would drain the next tile's prefetch.  The wave-
+// private epilogue area is never a DMA target, so no such wait is needed; asm LDS ops carry no memory operand.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ void lds_write_b64(unsigned addr, u32x2 v) {
+    asm volatile("ds_write_b64 %0, %1" :: "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
+    u32x4 d;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr) : "memory");
+    return d;
+}
+
+template <int MH, int NH>
+__device__ __forceinline__ void quad(f32x4 (&acc)[8][4], const bf16x8 (&af)[4][2], const bf16x8 (&wf)[2][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                             : "+v"(acc[MH * 4 + mi][NH * 2 + ni]) : "v"(wf[ni][kk]), "v"(af[mi][kk]));
+    __builtin_amdgcn_s_setprio(0);
+}
+
+}  // namespace
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256p_bf16_nt_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+
+    const int tiles_n = p.N >> 8;
+    const int ntiles = ((p.M + 255) >> 8) * tiles_n;
+    const int full = (ntiles / (int)gridDim.x) * (int)gridDim.x;     // tiles inside complete rounds
+    // logical tile of a work index: inside complete rounds every XCD (blocks b, b+8, ... by observed round-robin
+    // placement; speed only) gets a contiguous run of tiles so that its L2 sees few A / W panels at a time
+    auto tile_of = [&](int idx, int& row0, int& col0) {
+        int L = idx;
+        if (idx < full && (gridDim.x & 7) == 0) {
+            const int rnd = idx / (int)gridDim.x, b = idx - rnd * (int)gridDim.x;
+            L = rnd * (int)gridDim.x + (b & 7) * ((int)gridDim.x >> 3) + (b >> 3);
+        }
+        const int tm = L / tiles_n;
+        row0 = tm << 8;
+        col0 = (L - tm * tiles_n) << 8;
+    };
+
+    // staging addresses = wave-uniform tile base (SGPRs) + a per-lane 32-bit byte offset that never changes
+    const int srow = lane >> 3, schunk = lane & 7;
+    const int r0 = wid * 16 + srow, r1 = r0 + 8;
+    const unsigned a_lane0 = (unsigned)(r0 * p.lda + ((schunk ^ ((r0 >> 1) & 7)) << 3)) * 2u;
+    const unsigned a_lane1 = (unsigned)(r1 * p.lda + ((schunk ^ ((r1 >> 1) & 7)) << 3)) * 2u;
+    const unsigned w_lane0 = (unsigned)(r0 * p.ldw + ((schunk ^ ((r0 >> 1) & 7)) << 3)) * 2u;
+    const unsigned w_lane1 = (unsigned)(r1 * p.ldw + ((schunk ^ ((r1 >> 1) & 7)) << 3)) * 2u;
+    const size_t a_half = (size_t)256 * p.lda, w_half = (size_t)256 * p.ldw;      // bytes between the two half-tiles
+    char* const stage_base = smem + wid * 2048;
+
+    const char *a_tile, *w_tile;                        // wave-uniform
+    auto set_src = [&](int row0, int col0) {
+        a_tile = (const char*)p.A + (size_t)row0 * p.lda * 2;
+        w_tile = (const char*)p.W + (size_t)col0 * p.ldw * 2;
+    };
+    auto stage_a = [&](int half, int tau) {
+        char* dst = stage_base + (tau & 1) * PBUF + half * PHALF;
+        const char* src = a_tile + half * a_half + tau * 128;
+        glds16p(src + a_lane0, dst);
+        glds16p(src + a_lane1, dst + 1024);
+    };
+    auto stage_w = [&](int half, int tau) {
+        char* dst = stage_base + (tau & 1) * PBUF + (2 + half) * PHALF;
+        const char* src = w_tile + half * w_half + tau * 128;
+        glds16p(src + w_lane0, dst);
+        glds16p(src + w_lane1, dst + 1024);
+    };
+    auto prologue = [&](int col0_, int parity) {   // 10 LDS-DMA per lane (nt >= 2 is guaranteed by the launcher)
+        if (wid == 0 && p.bias) glds16p(p.bias + col0_ + lane * 4, smem + PBIAS + parity * 1024);
+        stage_a(0, 0); stage_a(1, 0); stage_w(0, 0); stage_w(1, 0); stage_w(0, 1);
+    };
+
+    const int lrow = lane & 15, lq = lane >> 4;
+    const int swz = lrow >> 1;
+    const int co0 = ((0 + lq) ^ swz) << 4, co1 = ((4 + lq) ^ swz) << 4;
+    const int a_off = wr * PHALF + lrow * 128;
+    const int b_off = 2 * PHALF + (wc >> 1) * PHALF + ((wc & 1) * 64 + lrow) * 128;
+    const int nt = p.K >> 6;
+
+    // epilogue addressing (wave-private 2 KiB: 16 rows x 128 B, 16-byte chunk ^= row & 7)
+    char* const epi = smem + PEPI + wid * 2048;
+    const int er = lane >> 3, ec = lane & 7;                          // read-back: row er (+8i), chunk ec
+    const unsigned c_lane = (unsigned)(er * p.ldc + ec * 8) * 2u;     // per-lane byte offset inside the C tile
+    const unsigned epi_w = lds_addr(epi) + lrow * 128 + (((lq >> 1) ^ (lrow & 7)) << 4) + (lq & 1) * 8;
+    const unsigned epi_r0 = lds_addr(epi) + er * 128 + ((ec ^ er) << 4);               // rows er and er + 8:
+    const unsigned epi_r1 = epi_r0 + 1024;                                           // (er + 8) & 7 == er
+
+    if (!p.bias && tid < 128) *(float4*)(smem + PBIAS + tid * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    int row0, col0;
+    tile_of(blockIdx.x, row0, col0);
+    set_src(row0, col0);
+    prologue(col0, 0);
+    bool first = true;
+    int parity = 0;
+
+    for (int idx = blockIdx.x; idx < ntiles; idx += gridDim.x) {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // K-tile 0 (and everything older) landed; B0(1) and, after the first tile, the previous 16 stores may fly
+        if (first) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        first = false;
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+
+        bf16x8 af[4][2], w0[2][2], w1[2][2];
+        for (int t = 0; t < nt; ++t) {
+            const char* sa = smem + (t & 1) * PBUF + a_off;
+            const char* sb = smem + (t & 1) * PBUF + b_off;
+            const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                w0[ni][0] = *(const bf16x8*)(sb + ni * 2048 + co0);
+                w0[ni][1] = *(const bf16x8*)(sb + ni * 2048 + co1);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                af[mi][0] = *(const bf16x8*)(sa + mi * 2048 + co0);
+                af[mi][1] = *(const bf16x8*)(sa + mi * 2048 + co1);
+            }
+            if (more1) stage_w(1, t + 1);
+            __builtin_amdgcn_s_barrier();
+            quad<0, 0>(acc, af, w0);
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                w1[ni][0] = *(const bf16x8*)(sb + 4096 + ni * 2048 + co0);
+                w1[ni][1] = *(const bf16x8*)(sb + 4096 + ni * 2048 + co1);
+            }
+            if (more1) stage_a(0, t + 1);
+            __builtin_amdgcn_s_barrier();
+            quad<0, 1>(acc, af, w1);
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                af[mi][0] = *(const bf16x8*)(sa + 8192 + mi * 2048 + co0);
+                af[mi][1] = *(const bf16x8*)(sa + 8192 + mi * 2048 + co1);
+            }
+            if (more1) stage_a(1, t + 1);
+            __builtin_amdgcn_s_barrier();
+            quad<1, 1>(acc, af, w1);
+            __builtin_amdgcn_s_barrier();
+            if (more2) stage_w(0, t + 2);
+            if (wr == 1) {
+                if (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            quad<1, 0>(acc, af, w0);
+            if (wr == 0) {
+                if (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();      // both halves are past their last LDS read: K buffers are free
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // asm MFMA result -> VALU read (>= 12 wait states)
+
+        // ---- hand-over: the next tile's first loads, then this tile's stores (bias comes from LDS)
+        const int ccol = col0 + wc * 64;
+        const int crow = row0 + wr * 128;
+        // bias of THIS tile out of LDS before the next tile's LDS-DMA is issued: hipcc guards a ds_read of a DMA-written
+        // LDS range with vmcnt(0); here nothing is in flight yet, after the prologue it would drain the prefetch
+        const float* sbias = (const float*)(smem + PBIAS + parity * 1024) + wc * 64 + lq * 4;
+        float4 bias[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bias[ni] = *(const float4*)(sbias + ni * 16);
+        const int nidx = idx + gridDim.x;
+        if (nidx < ntiles) {
+            tile_of(nidx, row0, col0);
+            set_src(row0, col0);
+            prologue(col0, parity ^ 1);
+        }
+        parity ^= 1;
+        char* const c_tile = (char*)p.C + ((size_t)crow * p.ldc + ccol) * 2;      // wave-uniform; lanes add c_lane
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {                 // 8 passes of 16 rows through the wave's private LDS area
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                f32x4 v = acc[mi][ni];
+                v[0] += bias[ni].x; v[1] += bias[ni].y; v[2] += bias[ni].z; v[3] += bias[ni].w;
+                if constexpr (EPI == EPI_BIAS_QGELU_BF16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[r]));
+                }
+                u32x2 o;
+                o[0] = pack_bf16x2(v[0], v[1]);
+                o[1] = pack_bf16x2(v[2], v[3]);
+                lds_write_b64(epi_w ^ (ni * 32), o);      // chunk (ni*2 + (lq>>1)) ^ (lrow & 7): ni only flips bits 5-6
+            }
+            u32x4 d0 = lds_read_b128(epi_r0), d1 = lds_read_b128(epi_r1);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0), "+v"(d1) :: "memory");
+            if (!(p.dbg & 1)) {
+                *(u32x4*)(c_tile + (size_t)(mi * 16) * p.ldc * 2 + c_lane) = d0;
+                *(u32x4*)(c_tile + (size_t)(mi * 16 + 8) * p.ldc * 2 + c_lane) = d1;
+            }
+        }
+    }
+}
+
+template <int EPI>
+static int launch256p(const GemmParams& p, hipStream_t stream) {
+    auto kern = gemm256p_bf16_nt_kernel<EPI>;
+    static bool attr_done = false;
+    static int num_cu = 0;
+    if (!attr_done) {
+        KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PSMEM));
+        int dev = 0;
+        KEMR_CHECK_HIP(hipGetDevice(&dev));
+        KEMR_CHECK_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        attr_done = true;
+    }
+    const int tiles = ((p.M + 255) / 256) * (p.N / 256);
+    const int grid = tiles < num_cu ? tiles : num_cu;
+    GemmParams q = p;
+    q.dbg = g_gemm_dbg;
+    ProfScope prof(PROF_GEMM, stream);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), PSMEM, stream, q);
+    KEMR_CHECK_LAUNCH("gemm256p_bf16_nt_kernel");
+    return KEMR_OK;
+}
+
+// C must have ceil256(M) rows: rows in [M, ceil256(M)) are written (with values computed from A's pad rows).
+int launch_gemm256p(const GemmParams& p, int epi, hipStream_t stream) {
+    switch (epi) {
+        case EPI_BIAS_BF16:       return launch256p<EPI_BIAS_BF16>(p, stream);
+        case EPI_BIAS_QGELU_BF16: return launch256p<EPI_BIAS_QGELU_BF16>(p, stream);
+    }
+    KEMR_FAIL(KEMR_ERR_INVALID, "gemm256p: epilogue %d is not a bf16-store epilogue", epi);
+}
+
+}  // namespace kemr
