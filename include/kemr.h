@@ -198,6 +198,9 @@ int kemr_op_gemm(const void* a_dev, const void* w_dev, const float* bias_dev, vo
                  int m, int n, int k, int epilogue, void* stream);
 int kemr_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, void* y_dev,
                       int rows, int width, int out_dtype /*KEMR_BF16|KEMR_F32*/, void* stream);
+/* fused residual form used inside the towers: x_f32 += delta_bf16 (written back), y_bf16 = LayerNorm(x) */
+int kemr_op_layernorm_resid(float* x_dev, const void* delta_dev, const float* gamma_dev, const float* beta_dev,
+                            void* y_dev, int rows, int width, void* stream);
 /* qkv bf16 [batch*t, 3*width] (q pre-scaled by 1/8) -> out bf16 [batch*t, width] */
 int kemr_op_attention(const void* qkv_dev, void* out_dev, int batch, int t, int width, int causal, void* stream);
 

@@ -283,11 +283,12 @@ struct Workspace {
     float* x;       // [Mp, W] fp32 residual stream
     bf16_t* h;      // [Mp, W] bf16: LayerNorm output / attention output (GEMM A operand)
     bf16_t* big;    // [Mp, 4W] bf16: qkv (ld 3W), MLP hidden (ld 4W), im2col patches
+    bf16_t* delta;  // [Mp, W] bf16: output of the out-proj / fc2 GEMMs, added to x by the next LayerNorm (or the tail)
 };
 
 size_t ws_bytes(int width, int tokens, int batch) {
     const int64_t Mp = round_up((int64_t)batch * tokens, 256);
-    return (size_t)(round_up(Mp * width * 4, 256) + round_up(Mp * width * 2, 256) + round_up(Mp * width * 8, 256));
+    return (size_t)(round_up(Mp * width * 4, 256) + 2 * round_up(Mp * width * 2, 256) + round_up(Mp * width * 8, 256));
 }
 
 int carve(Workspace& w, void* base, size_t bytes, int width, int tokens, int batch) {
@@ -298,29 +299,37 @@ int carve(Workspace& w, void* base, size_t bytes, int width, int tokens, int bat
     char* p = (char*)base;
     w.x = (float*)p; p += round_up(Mp * width * 4, 256);
     w.h = (bf16_t*)p; p += round_up(Mp * width * 2, 256);
+    w.delta = (bf16_t*)p; p += round_up(Mp * width * 2, 256);
     w.big = (bf16_t*)p;
     return KEMR_OK;
 }
 
-int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, hipStream_t s) {
+// Residual blocks.  The out-proj and fc2 GEMMs do not read-modify-write the fp32 residual stream: they store
+// `A.W^T + bias` as bf16 into `delta` (store-only epilogue, overlapped with the next tile by the persistent GEMM) and the
+// following LayerNorm applies x += delta while it reads x anyway.  On return `*pending` is the last block's delta that
+// the caller's tail still has to add.
+int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, hipStream_t s, const bf16_t** pending) {
     const int W = t.width, M = batch * t.tokens;
+    const bf16_t* carry = nullptr;
     for (int l = 0; l < t.layers; ++l) {
         const LayerW& L = t.layer[l];
-        KEMR_TRY(launch_layernorm(w.x, L.ln1_g, L.ln1_b, w.h, M, W, KEMR_BF16, s));
+        KEMR_TRY(launch_layernorm(w.x, carry, L.ln1_g, L.ln1_b, w.h, M, W, KEMR_BF16, s));
         GemmParams g{};
         g.M = M;
         g.c_rows_padded = 1;       // every workspace buffer has ceil256(M) rows
         g.A = w.h; g.lda = W; g.W = L.wqkv; g.ldw = W; g.bias = L.bqkv; g.C = w.big; g.ldc = 3 * W; g.N = 3 * W; g.K = W;
         KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
         KEMR_TRY(launch_attention(w.big, w.h, batch, t.tokens, W, causal, s));
-        g.A = w.h; g.lda = W; g.W = L.wo; g.ldw = W; g.bias = L.bo; g.C = w.x; g.ldc = W; g.N = W; g.K = W;
-        KEMR_TRY(launch_gemm(g, EPI_BIAS_RESID_F32, s));
-        KEMR_TRY(launch_layernorm(w.x, L.ln2_g, L.ln2_b, w.h, M, W, KEMR_BF16, s));
+        g.A = w.h; g.lda = W; g.W = L.wo; g.ldw = W; g.bias = L.bo; g.C = w.delta; g.ldc = W; g.N = W; g.K = W;
+        KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+        KEMR_TRY(launch_layernorm(w.x, w.delta, L.ln2_g, L.ln2_b, w.h, M, W, KEMR_BF16, s));
         g.A = w.h; g.lda = W; g.W = L.w1; g.ldw = W; g.bias = L.b1; g.C = w.big; g.ldc = 4 * W; g.N = 4 * W; g.K = W;
         KEMR_TRY(launch_gemm(g, EPI_BIAS_QGELU_BF16, s));
-        g.A = w.big; g.lda = 4 * W; g.W = L.w2; g.ldw = 4 * W; g.bias = L.b2; g.C = w.x; g.ldc = W; g.N = W; g.K = 4 * W;
-        KEMR_TRY(launch_gemm(g, EPI_BIAS_RESID_F32, s));
+        g.A = w.big; g.lda = 4 * W; g.W = L.w2; g.ldw = 4 * W; g.bias = L.b2; g.C = w.delta; g.ldc = W; g.N = W; g.K = 4 * W;
+        KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+        carry = w.delta;
     }
+    *pending = carry;
     return KEMR_OK;
 }
 
@@ -349,9 +358,10 @@ extern "C" int kemr_encode_image(kemr_model* m, const float* pixels_dev, int bat
     g.pos = m->vpos; g.patches = m->patches; g.M = batch * m->patches; g.N = W; g.K = m->kpad;
     KEMR_TRY(launch_gemm(g, EPI_PATCH_F32, s));
     KEMR_TRY(launch_cls_rows(w.x, m->cls, m->vpos, batch, T, W, s));
-    KEMR_TRY(launch_layernorm(w.x, m->lnpre_g, m->lnpre_b, w.x, batch * T, W, KEMR_F32, s));
-    KEMR_TRY(run_blocks(m->vis, w, batch, 0, s));
-    KEMR_TRY(launch_tail(w.x, nullptr, batch, T, W, m->lnpost_g, m->lnpost_b, m->vproj, m->cfg.embed_dim, normalize, out_dev, s));
+    KEMR_TRY(launch_layernorm(w.x, nullptr, m->lnpre_g, m->lnpre_b, w.x, batch * T, W, KEMR_F32, s));
+    const bf16_t* pending = nullptr;
+    KEMR_TRY(run_blocks(m->vis, w, batch, 0, s, &pending));
+    KEMR_TRY(launch_tail(w.x, pending, nullptr, batch, T, W, m->lnpost_g, m->lnpost_b, m->vproj, m->cfg.embed_dim, normalize, out_dev, s));
     return KEMR_OK;
 }
 
@@ -366,8 +376,9 @@ extern "C" int kemr_encode_text(kemr_model* m, const int32_t* ids_dev, int batch
     Workspace w;
     KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, T, batch));
     KEMR_TRY(launch_text_embed(ids_dev, m->tok, m->tpos, w.x, batch, T, W, m->cfg.vocab, s));
-    KEMR_TRY(run_blocks(m->txt, w, batch, 1, s));
-    KEMR_TRY(launch_tail(w.x, ids_dev, batch, T, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s));
+    const bf16_t* pending = nullptr;
+    KEMR_TRY(run_blocks(m->txt, w, batch, 1, s, &pending));
+    KEMR_TRY(launch_tail(w.x, pending, ids_dev, batch, T, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s));
     return KEMR_OK;
 }
 
@@ -424,7 +435,13 @@ extern "C" int kemr_op_gemm(const void* a_dev, const void* w_dev, const float* b
 extern "C" int kemr_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, void* y_dev, int rows,
                                  int width, int out_dtype, void* stream) {
     if (!x_dev || !gamma_dev || !beta_dev || !y_dev) KEMR_FAIL(KEMR_ERR_INVALID, "op_layernorm: null argument");
-    return launch_layernorm(x_dev, gamma_dev, beta_dev, y_dev, rows, width, out_dtype, (hipStream_t)stream);
+    return launch_layernorm((float*)x_dev, nullptr, gamma_dev, beta_dev, y_dev, rows, width, out_dtype, (hipStream_t)stream);
+}
+
+extern "C" int kemr_op_layernorm_resid(float* x_dev, const void* delta_dev, const float* gamma_dev, const float* beta_dev,
+                                       void* y_dev, int rows, int width, void* stream) {
+    if (!x_dev || !delta_dev || !gamma_dev || !beta_dev || !y_dev) KEMR_FAIL(KEMR_ERR_INVALID, "op_layernorm_resid: null argument");
+    return launch_layernorm(x_dev, (const bf16_t*)delta_dev, gamma_dev, beta_dev, y_dev, rows, width, KEMR_BF16, (hipStream_t)stream);
 }
 
 extern "C" int kemr_op_attention(const void* qkv_dev, void* out_dev, int batch, int t, int width, int causal, void* stream) {

@@ -86,7 +86,8 @@ int launch_gemm256p(const GemmParams& p, int epi, hipStream_t stream);  // gemm2
 extern int g_gemm_variant;   // 0 auto, 1 = 128x128 (gemm.hip), 2 / 3 = 256x256 lockstep / staggered, 4 = persistent 256x256 (bf16 epilogues)
 
 // ---- other launchers --------------------------------------------------------------------------
-int launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int rows, int width,
+// delta != nullptr: x += delta (bf16 [rows, width], the previous GEMM's output) is applied first and written back
+int launch_layernorm(float* x, const bf16_t* delta, const float* gamma, const float* beta, void* y, int rows, int width,
                      int out_dtype, hipStream_t stream);
 int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int t, int width, int causal, hipStream_t stream);
 int launch_im2col(const float* pixels, bf16_t* patches, int batch, int image_size, int patch, int kpad, hipStream_t stream);
@@ -94,7 +95,8 @@ int launch_cls_rows(float* x, const float* class_emb, const float* pos, int batc
 int launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos, float* x, int batch, int ctx,
                       int width, int vocab, hipStream_t stream);
 // pooled row -> LayerNorm -> @ proj [width, d] -> optional L2 normalise.  ids == nullptr: row = b * tokens (CLS)
-int launch_tail(const float* x, const int32_t* ids, int batch, int tokens, int width, const float* gamma,
+// delta (optional): the last block's pending residual update, added to the pooled row
+int launch_tail(const float* x, const bf16_t* delta, const int32_t* ids, int batch, int tokens, int width, const float* gamma,
                 const float* beta, const float* proj, int d, int normalize, float* out, hipStream_t stream);
 
 }  // namespace kemr

@@ -105,7 +105,8 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // grid (ceil(d / 64), batch): every workgroup re-normalises its row (width <= 1280 floats, trivial) so that no
 // intermediate buffer is needed; wave w owns 16 columns, lane (g = lane >> 2, jq = lane & 3) accumulates columns
 // 4*jq..4*jq+3 over the rows i = g (mod 16) with 16-byte loads of the fp32 projection, then 4 shuffle steps.
-__global__ __launch_bounds__(256) void tail_proj_kernel(const float* __restrict__ x, const int32_t* __restrict__ ids,
+__global__ __launch_bounds__(256) void tail_proj_kernel(const float* __restrict__ x, const bf16_t* __restrict__ delta,
+                                                        const int32_t* __restrict__ ids,
                                                         int tokens, int width, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ proj,
                                                         int d, float* __restrict__ out) {
@@ -133,15 +134,21 @@ __global__ __launch_bounds__(256) void tail_proj_kernel(const float* __restrict_
         if (tid == 0) *pool = best_t;
     }
     __syncthreads();
-    const float* xr = x + ((size_t)b * tokens + *pool) * width;
+    const size_t prow = (size_t)b * tokens + *pool;
+    const float* xr = x + prow * width;
+    const bf16_t* dr = delta ? delta + prow * width : nullptr;
 
     float s = 0.f;
-    for (int i = tid; i < width; i += 256) s += xr[i];
+    for (int i = tid; i < width; i += 256) {           // pooled row (+ the pending residual update) into LDS
+        const float v = xr[i] + (dr ? bf16_to_f32(dr[i]) : 0.f);
+        y[i] = v;
+        s += v;
+    }
     const float mean = block_sum(s, red) / width;
     float q = 0.f;
-    for (int i = tid; i < width; i += 256) { const float c = xr[i] - mean; q += c * c; }
+    for (int i = tid; i < width; i += 256) { const float c = y[i] - mean; q += c * c; }
     const float rstd = 1.0f / sqrtf(block_sum(q, red) / width + 1e-5f);
-    for (int i = tid; i < width; i += 256) y[i] = (xr[i] - mean) * rstd * gamma[i] + beta[i];
+    for (int i = tid; i < width; i += 256) y[i] = (y[i] - mean) * rstd * gamma[i] + beta[i];
     __syncthreads();
 
     const int j = blockIdx.x * 64 + wid * 16 + (lane & 3) * 4;     // first of this lane's 4 columns
@@ -175,14 +182,14 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x,
     for (int i = lane; i < d; i += 64) r[i] *= inv;
 }
 
-int launch_tail(const float* x, const int32_t* ids, int batch, int tokens, int width, const float* gamma,
+int launch_tail(const float* x, const bf16_t* delta, const int32_t* ids, int batch, int tokens, int width, const float* gamma,
                 const float* beta, const float* proj, int d, int normalize, float* out, hipStream_t stream) {
     if (batch <= 0) return KEMR_OK;
     if (d % 4 != 0 || d <= 0) KEMR_FAIL(KEMR_ERR_INVALID, "tail: embed_dim %d must be a positive multiple of 4", d);
     if (batch > 65535) KEMR_FAIL(KEMR_ERR_INVALID, "tail: batch %d > 65535", batch);
     const size_t smem = (size_t)width * 4 + 32;
     ProfScope prof(PROF_OTHER, stream);
-    hipLaunchKernelGGL(tail_proj_kernel, dim3((d + 63) / 64, batch), dim3(256), smem, stream, x, ids, tokens, width, gamma,
+    hipLaunchKernelGGL(tail_proj_kernel, dim3((d + 63) / 64, batch), dim3(256), smem, stream, x, delta, ids, tokens, width, gamma,
                        beta, proj, d, out);
     KEMR_CHECK_LAUNCH("tail_proj_kernel");
     if (normalize) {

@@ -6,19 +6,29 @@
 
 namespace kemr {
 
-template <int NV, typename OutT>   // width = NV * 256
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, OutT* y, int rows, float eps) {
+// RESID: the residual update of the preceding GEMM is fused here.  That GEMM stored its output (bias included) as a
+// bf16 "delta" (store-only epilogue, overlapped by the persistent GEMM kernel); this kernel computes x += delta, writes
+// the fp32 residual stream back and normalises the updated row: 4 + 2 bytes read, 4 + 2 written per element.
+template <int NV, typename OutT, bool RESID>   // width = NV * 256
+__global__ __launch_bounds__(256) void layernorm_kernel(float* x, const bf16_t* __restrict__ delta,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        OutT* y, int rows, float eps) {
     constexpr int W = NV * 256;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float4* xr = (const float4*)(x + (size_t)row * W);
+    float4* xr = (float4*)(x + (size_t)row * W);
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         v[i] = xr[i * 64 + lane];
+        if constexpr (RESID) {
+            const uint2 d = ((const uint2*)(delta + (size_t)row * W))[i * 64 + lane];
+            v[i].x += bf16_to_f32((bf16_t)(d.x & 0xffff)); v[i].y += bf16_to_f32((bf16_t)(d.x >> 16));
+            v[i].z += bf16_to_f32((bf16_t)(d.y & 0xffff)); v[i].w += bf16_to_f32((bf16_t)(d.y >> 16));
+            xr[i * 64 + lane] = v[i];
+        }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) * (1.0f / W);
@@ -50,27 +60,32 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 }
 
 template <int NV>
-static int launch_nv(const float* x, const float* g, const float* b, void* y, int rows, int out_dtype, hipStream_t s) {
+static int launch_nv(float* x, const bf16_t* delta, const float* g, const float* b, void* y, int rows, int out_dtype,
+                     hipStream_t s) {
     const int blocks = (rows + 3) / 4;
     ProfScope prof(PROF_LAYERNORM, s);
-    if (out_dtype == KEMR_BF16)
-        hipLaunchKernelGGL((layernorm_kernel<NV, bf16_t>), dim3(blocks), dim3(256), 0, s, x, g, b, (bf16_t*)y, rows, 1e-5f);
+    if (delta)
+        hipLaunchKernelGGL((layernorm_kernel<NV, bf16_t, true>), dim3(blocks), dim3(256), 0, s, x, delta, g, b, (bf16_t*)y, rows, 1e-5f);
+    else if (out_dtype == KEMR_BF16)
+        hipLaunchKernelGGL((layernorm_kernel<NV, bf16_t, false>), dim3(blocks), dim3(256), 0, s, x, delta, g, b, (bf16_t*)y, rows, 1e-5f);
     else
-        hipLaunchKernelGGL((layernorm_kernel<NV, float>), dim3(blocks), dim3(256), 0, s, x, g, b, (float*)y, rows, 1e-5f);
+        hipLaunchKernelGGL((layernorm_kernel<NV, float, false>), dim3(blocks), dim3(256), 0, s, x, delta, g, b, (float*)y, rows, 1e-5f);
     KEMR_CHECK_LAUNCH("layernorm_kernel");
     return KEMR_OK;
 }
 
-int launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int rows, int width,
+// delta != nullptr: x += delta first (x is updated in place; the output is bf16)
+int launch_layernorm(float* x, const bf16_t* delta, const float* gamma, const float* beta, void* y, int rows, int width,
                      int out_dtype, hipStream_t stream) {
     if (rows <= 0) return KEMR_OK;
     if (out_dtype != KEMR_BF16 && out_dtype != KEMR_F32) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: bad out dtype %d", out_dtype);
+    if (delta && out_dtype != KEMR_BF16) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: the residual form writes bf16");
     switch (width) {
-        case 256:  return launch_nv<1>(x, gamma, beta, y, rows, out_dtype, stream);
-        case 512:  return launch_nv<2>(x, gamma, beta, y, rows, out_dtype, stream);
-        case 768:  return launch_nv<3>(x, gamma, beta, y, rows, out_dtype, stream);
-        case 1024: return launch_nv<4>(x, gamma, beta, y, rows, out_dtype, stream);
-        case 1280: return launch_nv<5>(x, gamma, beta, y, rows, out_dtype, stream);
+        case 256:  return launch_nv<1>(x, delta, gamma, beta, y, rows, out_dtype, stream);
+        case 512:  return launch_nv<2>(x, delta, gamma, beta, y, rows, out_dtype, stream);
+        case 768:  return launch_nv<3>(x, delta, gamma, beta, y, rows, out_dtype, stream);
+        case 1024: return launch_nv<4>(x, delta, gamma, beta, y, rows, out_dtype, stream);
+        case 1280: return launch_nv<5>(x, delta, gamma, beta, y, rows, out_dtype, stream);
     }
     KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: width %d not in {256,512,768,1024,1280}", width);
 }

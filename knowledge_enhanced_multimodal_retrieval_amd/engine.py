@@ -320,6 +320,18 @@ def op_layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_b
     return y
 
 
+def op_layernorm_resid(x: torch.Tensor, delta: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    """x (fp32, updated in place) += delta (bf16); returns LayerNorm(x) as bf16."""
+    L = _lib.lib()
+    rows, width = x.shape
+    y = torch.empty((rows, width), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(L.kemr_op_layernorm_resid(C.c_void_p(x.data_ptr()), C.c_void_p(delta.data_ptr()), C.c_void_p(gamma.data_ptr()),
+                                             C.c_void_p(beta.data_ptr()), C.c_void_p(y.data_ptr()), rows, width,
+                                             C.c_void_p(_stream_ptr(x.device))), "op_layernorm_resid")
+    return y
+
+
 def op_attention(qkv: torch.Tensor, batch: int, t: int, width: int, causal: bool) -> torch.Tensor:
     L = _lib.lib()
     out = torch.empty((batch * t, width), dtype=torch.bfloat16, device=qkv.device)

@@ -141,6 +141,22 @@ def test_layernorm(device, width, out_bf16):
         assert float((xd.cpu() - ref).abs().max()) < tol
 
 
+@pytest.mark.parametrize("width", [256, 768, 1024])
+def test_layernorm_with_fused_residual(device, width):
+    g = torch.Generator().manual_seed(width + 1)
+    rows = 301
+    x = torch.randn(rows, width, generator=g) * 2
+    delta = (torch.randn(rows, width, generator=g) * 0.5).to(torch.bfloat16)
+    gamma, beta = 1 + 0.1 * torch.randn(width, generator=g), 0.1 * torch.randn(width, generator=g)
+    xs = x + delta.float()
+    ref = torch.nn.functional.layer_norm(xs, (width,), gamma, beta, 1e-5)
+    xd = x.clone().to(device)
+    y = engine.op_layernorm_resid(xd, delta.to(device), gamma.to(device), beta.to(device))
+    torch.cuda.synchronize()
+    assert torch.equal(xd.cpu(), xs)                                  # residual stream updated in place, exactly
+    assert float((y.float().cpu() - ref).abs().max()) < 2e-2
+
+
 def _attention_ref(qkv, batch, t, width, causal):
     heads = width // 64
     q, k, v = qkv.float().view(batch, t, 3, heads, 64).permute(2, 0, 3, 1, 4)      # [B,H,T,64]; q already scaled
