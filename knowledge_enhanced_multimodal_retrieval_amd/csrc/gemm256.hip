@@ -50,6 +50,7 @@ __device__ __forceinline__ void quadrant(f32x4 (&acc)[8][4], const bf16x8 (&af)[
 template <int MH, int NH>
 __device__ __forceinline__ void quadrant_pinned(f32x4 (&acc)[8][4], const bf16x8 (&af)[4][2], const bf16x8 (&wf)[2][2]) {
     __builtin_amdgcn_s_setprio(1);
+    asm volatile("s_nop 1" ::: "memory");      // any compiler VALU write just above -> first asm MFMA operand read
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -269,7 +270,10 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_nt_kernel(const GemmPara
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < 4; ++ni) {
+            acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            asm volatile("" : "+v"(acc[mi][ni]));     // zero materialised here, far from the asm MFMAs (see gemm256p.hip)
+        }
 
     const int nt = p.K >> 6;
     stage_a(0, 0); stage_a(1, 0); stage_w(0, 0); stage_w(1, 0);

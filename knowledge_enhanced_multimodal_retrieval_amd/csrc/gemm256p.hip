@@ -8,10 +8,12 @@
 // as volatile asm, counted vmcnt).  LDS: 128 KiB K-tile double buffer + 16 KiB epilogue area (2 KiB private per wave) + 2 x 1 KiB bias.
 //
 // Tile hand-over, in issue order per lane (vmcnt counts loads, LDS-DMA and stores together, in order):
-//   [wave 0: 1 LDS-DMA of the next tile's 256 bias floats] [10 LDS-DMA: A0,A1,B0,B1 of K-tile 0 and B0 of K-tile 1 of
-//   the NEXT tile] [16 stores of THIS tile]
-// No register-destination load exists in the kernel, so hipcc inserts no vmcnt wait of its own; the next tile enters its
-// K loop behind `s_waitcnt vmcnt(18)` = everything up to B1(0) landed, B0(1) and the 16 stores still in flight.
+//   [wave 0: 1 LDS-DMA of the next tile's 256 bias floats] [16 LDS-DMA: K-tiles 0 and 1 of the NEXT tile, both K buffers
+//   are free] [16 stores of THIS tile]
+// No register-destination load exists in the kernel, so hipcc inserts no vmcnt wait of its own.  The next tile enters
+// its K loop behind `vmcnt(24)` (K-tile 0 landed; K-tile 1 and the stores in flight) and closes K-tile 0 behind
+// `vmcnt(18)` (K-tile 1 landed; B0(2) and the stores in flight): the stores get two K-tiles of time before the first
+// wait that is ordered behind them (the one closing K-tile 1).
 // Every lane issues exactly 16 stores per tile (rows beyond M are NOT masked: C must have ceil256(M) rows), so the
 // count is exact.  The epilogue goes through the wave's private LDS area so that each store instruction writes
 // 8 full 128-byte lines (acc -> +bias -> act -> bf16 -> ds_write_b64, chunk-XOR swizzled -> ds_read_b128 -> 16 B / lane).
@@ -41,7 +43,9 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
 __device__ __forceinline__ void lds_write_b64(unsigned addr, u32x2 v) {
-    asm volatile("ds_write_b64 %0, %1" :: "v"(addr), "v"(v) : "memory");
+    // the trailing s_nop keeps hipcc from overwriting the data registers while the LDS unit still reads them (observed:
+    // a packed VALU op right behind the asm store corrupted the second data dword; cdna guide 5.7 item 1, "Stores")
+    asm volatile("ds_write_b64 %0, %1\n\ts_nop 2" :: "v"(addr), "v"(v) : "memory");
 }
 __device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
     u32x4 d;
@@ -52,6 +56,7 @@ __device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
 template <int MH, int NH>
 __device__ __forceinline__ void quad(f32x4 (&acc)[8][4], const bf16x8 (&af)[4][2], const bf16x8 (&wf)[2][2]) {
     __builtin_amdgcn_s_setprio(1);
+    asm volatile("s_nop 1" ::: "memory");      // any compiler VALU write just above -> first asm MFMA operand read
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -115,9 +120,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_nt_kernel(const GemmPara
         glds16p(src + w_lane0, dst);
         glds16p(src + w_lane1, dst + 1024);
     };
-    auto prologue = [&](int col0_, int parity) {   // 10 LDS-DMA per lane (nt >= 2 is guaranteed by the launcher)
+    auto prologue = [&](int col0_, int parity) {   // K-tiles 0 and 1 complete: 16 LDS-DMA per lane (nt >= 2)
         if (wid == 0 && p.bias) glds16p(p.bias + col0_ + lane * 4, smem + PBIAS + parity * 1024);
-        stage_a(0, 0); stage_a(1, 0); stage_w(0, 0); stage_w(1, 0); stage_w(0, 1);
+        stage_a(0, 0); stage_a(1, 0); stage_w(0, 0); stage_w(1, 0);
+        stage_w(0, 1); stage_w(1, 1); stage_a(0, 1); stage_a(1, 1);
     };
 
     const int lrow = lane & 15, lq = lane >> 4;
@@ -148,11 +154,19 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_nt_kernel(const GemmPara
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ni = 0; ni < 4; ++ni) {
+                acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // materialise the zero HERE: hipcc cannot see that the asm below is an MFMA and otherwise sinks the
+                // v_mov right in front of the first use, inside the VALU-write -> MFMA-SrcC hazard window (observed:
+                // accumulator elements 2,3 of one fragment started from stale register contents)
+                asm volatile("" : "+v"(acc[mi][ni]));
+            }
 
-        // K-tile 0 (and everything older) landed; B0(1) and, after the first tile, the previous 16 stores may fly
-        if (first) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        // K-tile 0 (and everything older) landed; K-tile 1 (8 DMA) and, after the first tile, the 16 stores may fly
+        const bool had_stores = !first;
+        if (first) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        if (p.dbg & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // bisecting aid: drain everything
         first = false;
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();
@@ -161,7 +175,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_nt_kernel(const GemmPara
         for (int t = 0; t < nt; ++t) {
             const char* sa = smem + (t & 1) * PBUF + a_off;
             const char* sb = smem + (t & 1) * PBUF + b_off;
-            const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+            // K-tile 1 came with the prologue; the stores of the previous tile are older than everything staged in this
+            // loop but younger than K-tile 1, so the wait that closes K-tile 0 may leave them (and B0(2)) in flight
+            const bool more1 = t + 1 < nt && t > 0, more2 = t + 2 < nt;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 w0[ni][0] = *(const bf16x8*)(sb + ni * 2048 + co0);
@@ -195,16 +211,20 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_nt_kernel(const GemmPara
             quad<1, 1>(acc, af, w1);
             __builtin_amdgcn_s_barrier();
             if (more2) stage_w(0, t + 2);
-            if (wr == 1) {
-                if (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            auto close_tile = [&]() {
+                if (p.dbg & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (t == 0 && had_stores) {
+                    if (more2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                } else {
+                    if (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            };
+            if (wr == 1) close_tile();
             __builtin_amdgcn_s_barrier();
             quad<1, 0>(acc, af, w0);
-            if (wr == 0) {
-                if (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            if (wr == 0) close_tile();
             __builtin_amdgcn_s_barrier();
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();      // both halves are past their last LDS read: K buffers are free

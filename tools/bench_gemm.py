@@ -7,9 +7,9 @@ from knowledge_enhanced_multimodal_retrieval_amd import _lib, engine
 
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 255
-shapes = [("v.qkv", B * 257, 3072, 1024, 0), ("v.out", B * 257, 1024, 1024, 2), ("v.fc1", B * 257, 4096, 1024, 1),
-          ("v.fc2", B * 257, 1024, 4096, 2), ("t.qkv", 2 * B * 77, 2304, 768, 0), ("t.out", 2 * B * 77, 768, 768, 2),
-          ("t.fc1", 2 * B * 77, 3072, 768, 1), ("t.fc2", 2 * B * 77, 768, 3072, 2), ("sq4096", 4096, 4096, 4096, 0)]
+shapes = [("v.qkv", B * 257, 3072, 1024, 0), ("v.out", B * 257, 1024, 1024, 0), ("v.fc1", B * 257, 4096, 1024, 1),
+          ("v.fc2", B * 257, 1024, 4096, 0), ("t.qkv", 2 * B * 77, 2304, 768, 0), ("t.out", 2 * B * 77, 768, 768, 0),
+          ("t.fc1", 2 * B * 77, 3072, 768, 1), ("t.fc2", 2 * B * 77, 768, 3072, 0), ("sq4096", 4096, 4096, 4096, 0)]
 g = torch.Generator(device=dev).manual_seed(0)
 res = {}
 for name, m, n, k, epi in shapes:
