@@ -21,9 +21,13 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)p);
 }
 
-template <int NT32, bool CAUSAL>   // keys padded to NT32 * 32
+// TC > 0: the sequence length is a compile-time constant (257 / 77: the shapes that matter), so every pad-key mask and
+// tile-skip test folds away; TC == 0 keeps T a run-time value (other models, tests).  With a run-time T the uniform
+// conditions of the 18 unrolled tiles overflowed the SGPR file (150+ v_readlane/v_writelane spills per query tile).
+template <int NT32, bool CAUSAL, int TC>   // keys padded to NT32 * 32
 __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                           int T, int width) {
+                                                           int T_rt, int width) {
+    const int T = TC > 0 ? TC : T_rt;
     constexpr int TP = NT32 * 32;
     constexpr int NT16 = NT32 * 2;
     constexpr int NCH = (TP * 8 + 255) / 256;          // 16-byte chunks of K (and of V) per thread
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
                 vf[4] = vb[0]; vf[5] = vb[1]; vf[6] = vb[2]; vf[7] = vb[3];
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf.v, o[dt], 0, 0, 0);
             }
+            if (u & 1) __builtin_amdgcn_sched_barrier(0);   // bound the V-fragment live ranges (else every tr read is hoisted)
         }
         // o[dt][r] = O[query lrow][d = dt*16 + lq*4 + r]
         if (q < T) {
@@ -166,15 +171,11 @@ static int launch_nt(const bf16_t* qkv, bf16_t* out, int batch, int t, int width
     constexpr int smem = NT32 * 32 * 128 * 2;
     const dim3 grid(width / 64, batch);
     ProfScope prof(PROF_ATTENTION, stream);
-    if (causal) {
-        auto kern = attention_kernel<NT32, true>;
-        KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, qkv, out, t, width);
-    } else {
-        auto kern = attention_kernel<NT32, false>;
-        KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, qkv, out, t, width);
-    }
+    void (*kern)(const bf16_t*, bf16_t*, int, int);
+    if (causal) kern = (NT32 == 3 && t == 77) ? attention_kernel<NT32, true, NT32 == 3 ? 77 : 0> : attention_kernel<NT32, true, 0>;
+    else kern = (NT32 == 9 && t == 257) ? attention_kernel<NT32, false, NT32 == 9 ? 257 : 0> : attention_kernel<NT32, false, 0>;
+    KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, qkv, out, t, width);
     KEMR_CHECK_LAUNCH("attention_kernel");
     return KEMR_OK;
 }

@@ -38,8 +38,16 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     uint32_t u = __float_as_uint(f);
     return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
+// two fp32 -> packed bf16x2 (RNE) in ONE instruction: hipcc lowers the vector cast to v_cvt_pk_bf16_f32 on gfx950
+typedef __bf16 kemr_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float kemr_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const kemr_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, kemr_bf16x2_t));
+}
+// QuickGELU x * sigmoid(1.702 x) with v_exp_f32 / v_rcp_f32 (exp2 with the constant folded; rcp is 1 ulp)
+__device__ __forceinline__ float quick_gelu(float v) {
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v));
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_kernel(const GemmPa
             }
             if constexpr (EPI == EPI_BIAS_QGELU_BF16) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[r]));
+                for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
             }
             if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16) {
                 uint2 o;

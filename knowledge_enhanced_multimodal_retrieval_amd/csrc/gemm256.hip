@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_nt_kernel(const GemmParam
             }
             if constexpr (EPI == EPI_BIAS_QGELU_BF16) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[r]));
+                for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
             }
             if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16) {
                 uint2 o;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_nt_kernel(const GemmPara
             }
             if constexpr (EPI == EPI_BIAS_QGELU_BF16) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[r]));
+                for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
             }
             if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16) {
                 uint2 o;

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_nt_kernel(const GemmPara
                 v[0] += bias[ni].x; v[1] += bias[ni].y; v[2] += bias[ni].z; v[3] += bias[ni].w;
                 if constexpr (EPI == EPI_BIAS_QGELU_BF16) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[r]));
+                    for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
                 }
                 u32x2 o;
                 o[0] = pack_bf16x2(v[0], v[1]);
