@@ -52,24 +52,32 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) qn[kk] = *(const bf16x8*)(base + (size_t)qc * ld + kk * 32 + lq * 8);
     }
-    // stage K then V: all global loads of a matrix in flight together, then the swizzled LDS writes
-#pragma unroll
-    for (int mat = 0; mat < 2; ++mat) {
-        uint4 v[NCH];
+    // stage K and V: ALL global loads of both matrices in flight together (one latency, not two), then the swizzled
+    // LDS writes.  (PMC: with K-then-V staging the waves sat 56 % of their life in s_waitcnt.)
+    {
+        uint4 kv[NCH], vv[NCH];
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int idx = tid + i * 256;
             const int row = idx >> 3, c = idx & 7;
-            v[i] = make_uint4(0, 0, 0, 0);
-            if (idx < TP * 8 && row < T) v[i] = *(const uint4*)(base + (size_t)row * ld + (mat + 1) * width + c * 8);
+            // branch-free: pad rows load the last valid row and are zeroed by a select at the LDS write (a conditional
+            // load, or a select right here, makes hipcc wait for the loads in the middle of the batch)
+            const int rc = row < T ? row : T - 1;
+            kv[i] = *(const uint4*)(base + (size_t)rc * ld + width + c * 8);
+            vv[i] = *(const uint4*)(base + (size_t)rc * ld + 2 * width + c * 8);
+
         }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int idx = tid + i * 256;
             const int row = idx >> 3, c = idx & 7;
             if (idx < TP * 8) {
-                if (mat == 0) *(uint4*)(sK + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v[i];
-                else          *(uint4*)(sV + row * 128 + ((c ^ (((row >> 1) & 3) << 1)) << 4)) = v[i];
+                const unsigned keep = row < T ? 0xffffffffu : 0u;       // component-wise: a struct select went to scratch
+                uint4 a = kv[i], b2 = vv[i];
+                a.x &= keep; a.y &= keep; a.z &= keep; a.w &= keep;
+                b2.x &= keep; b2.y &= keep; b2.z &= keep; b2.w &= keep;
+                *(uint4*)(sK + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = a;
+                *(uint4*)(sV + row * 128 + ((c ^ (((row >> 1) & 3) << 1)) << 4)) = b2;
             }
         }
     }
@@ -85,17 +93,35 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
             for (int kk = 0; kk < 2; ++kk) qn[kk] = *(const bf16x8*)(base + (size_t)qc * ld + kk * 32 + lq * 8);
         }
 
+        // S^T tiles in groups of G key tiles, K fragments double-buffered in registers: the reads of group g+1 are in
+        // flight while the MFMAs of group g issue (hipcc otherwise emits read-wait-MFMA per tile on ONE register set
+        // and exposes the LDS latency 18 times per query tile)
+        constexpr int G = (NT16 % 3 == 0) ? 3 : 2;
+        constexpr int NG = NT16 / G;
         f32x4 s[NT16];
+        bf16x8 kfr[2][G][2];
+        auto load_group = [&](int g, bf16x8 (&dst)[G][2]) {
 #pragma unroll
-        for (int t = 0; t < NT16; ++t) {
-            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (t * 16 < T) {                          // tiles made only of pad keys are skipped (uniform)
+            for (int j = 0; j < G; ++j)
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const bf16x8 kf = *(const bf16x8*)(sK + (t * 16 + lrow) * 128 + (((kk * 4 + lq) ^ (lrow >> 1)) << 4));
-                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
+                for (int kk = 0; kk < 2; ++kk)
+                    dst[j][kk] = *(const bf16x8*)(sK + ((g * G + j) * 16 + lrow) * 128 + (((kk * 4 + lq) ^ (lrow >> 1)) << 4));
+        };
+        load_group(0, kfr[0]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG && (g + 1) * G * 16 < T) load_group(g + 1, kfr[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int t = g * G + j;
+                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (t * 16 < T) {                      // tiles made only of pad keys are skipped (uniform)
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[g & 1][j][0], qf[0], s[t], 0, 0, 0);
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[g & 1][j][1], qf[1], s[t], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // s[t][r] = S[query lrow][key t*16 + lq*4 + r]
         float mx = -INFINITY;
@@ -129,14 +155,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < NT32; ++u) {
-            if (u * 32 >= T) continue;                 // all-pad key block (uniform)
-            union { bf16x8 v; uint32_t w[4]; } pf;
-            pf.w[0] = pack_bf16x2(s[2 * u][0], s[2 * u][1]);
-            pf.w[1] = pack_bf16x2(s[2 * u][2], s[2 * u][3]);
-            pf.w[2] = pack_bf16x2(s[2 * u + 1][0], s[2 * u + 1][1]);
-            pf.w[3] = pack_bf16x2(s[2 * u + 1][2], s[2 * u + 1][3]);
+        // O^T += V^T . P^T per 32-key block, V fragments double-buffered the same way
+        bf16x8 vfr[2][4];
+        auto load_v = [&](int u, bf16x8 (&dst)[4]) {
             const int ra = u * 32 + lq * 4 + (lrow >> 2);       // rows 32u + 4lq .. +3 (first half of the k slots)
             const int rb = ra + 16;                             // rows 32u + 16 + 4lq .. +3
 #pragma unroll
@@ -144,12 +165,25 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
                 const int c = dt * 2 + ((lrow & 3) >> 1);
                 const bf16x4 va = lds_read_tr16(sV + ra * 128 + ((c ^ (((ra >> 1) & 3) << 1)) << 4) + (lrow & 1) * 8);
                 const bf16x4 vb = lds_read_tr16(sV + rb * 128 + ((c ^ (((rb >> 1) & 3) << 1)) << 4) + (lrow & 1) * 8);
-                bf16x8 vf;
-                vf[0] = va[0]; vf[1] = va[1]; vf[2] = va[2]; vf[3] = va[3];
-                vf[4] = vb[0]; vf[5] = vb[1]; vf[6] = vb[2]; vf[7] = vb[3];
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf.v, o[dt], 0, 0, 0);
+                dst[dt][0] = va[0]; dst[dt][1] = va[1]; dst[dt][2] = va[2]; dst[dt][3] = va[3];
+                dst[dt][4] = vb[0]; dst[dt][5] = vb[1]; dst[dt][6] = vb[2]; dst[dt][7] = vb[3];
             }
-            if (u & 1) __builtin_amdgcn_sched_barrier(0);   // bound the V-fragment live ranges (else every tr read is hoisted)
+        };
+        load_v(0, vfr[0]);
+#pragma unroll
+        for (int u = 0; u < NT32; ++u) {
+            if (u * 32 >= T) continue;                 // all-pad key block (uniform)
+            if (u + 1 < NT32 && (u + 1) * 32 < T) load_v(u + 1, vfr[(u + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            union { bf16x8 v; uint32_t w[4]; } pf;
+            pf.w[0] = pack_bf16x2(s[2 * u][0], s[2 * u][1]);
+            pf.w[1] = pack_bf16x2(s[2 * u][2], s[2 * u][3]);
+            pf.w[2] = pack_bf16x2(s[2 * u + 1][0], s[2 * u + 1][1]);
+            pf.w[3] = pack_bf16x2(s[2 * u + 1][2], s[2 * u + 1][3]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[u & 1][dt], pf.v, o[dt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // o[dt][r] = O[query lrow][d = dt*16 + lq*4 + r]
         if (q < T) {
