@@ -91,6 +91,7 @@ extern int g_gemm_dbg;
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);      // picks the tile variant
 int launch_gemm256(const GemmParams& p, int epi, hipStream_t stream);   // gemm256.hip: 256x256x64, 8 waves, counted vmcnt
 int launch_gemm256p(const GemmParams& p, int epi, hipStream_t stream);  // gemm256p.hip: persistent, async epilogue (bf16-store epilogues)
+int launch_gemm256q(const GemmParams& p, int epi, hipStream_t stream);  // gemm256q.hip: persistent, 2 long phases per K-tile
 extern int g_gemm_variant;   // 0 auto, 1 = 128x128 (gemm.hip), 2 / 3 = 256x256 lockstep / staggered, 4 = persistent 256x256 (bf16 epilogues)
 
 // ---- other launchers --------------------------------------------------------------------------

@@ -1,22 +1,16 @@
-// Persistent bf16 GEMM for the bf16-output epilogues (bias, bias + QuickGELU): one 512-thread workgroup per CU walks
-// 256 x 256 output tiles; the epilogue of tile i overlaps the first K-tile loads of tile i+1 and its stores drain
-// behind the next tile's main loop.  Measured motivation (tools/bench_gemm_dbg.py): with the stores removed the
-// 256x256 kernels run the K = 1024 encoder shapes at ~1.34 PFLOP/s, with them at 0.57-0.91 -- the un-overlapped,
-// 8-byte-per-lane store tail was 30-58 % of the time.
-//
-// K loop: the staggered schedule of gemm256.hip (two barriers per phase, wr == 1 half one interval behind, MFMAs pinned
-// as volatile asm, counted vmcnt).  LDS: 128 KiB K-tile double buffer + 16 KiB epilogue area (2 KiB private per wave) + 2 x 1 KiB bias.
-//
-// Tile hand-over, in issue order per lane (vmcnt counts loads, LDS-DMA and stores together, in order):
-//   [wave 0: 1 LDS-DMA of the next tile's 256 bias floats] [16 LDS-DMA: K-tiles 0 and 1 of the NEXT tile, both K buffers
-//   are free] [16 stores of THIS tile]
-// No register-destination load exists in the kernel, so hipcc inserts no vmcnt wait of its own.  The next tile enters
-// its K loop behind `vmcnt(24)` (K-tile 0 landed; K-tile 1 and the stores in flight) and closes K-tile 0 behind
-// `vmcnt(18)` (K-tile 1 landed; B0(2) and the stores in flight): the stores get two K-tiles of time before the first
-// wait that is ordered behind them (the one closing K-tile 1).
-// Every lane issues exactly 16 stores per tile (rows beyond M are NOT masked: C must have ceil256(M) rows), so the
-// count is exact.  The epilogue goes through the wave's private LDS area so that each store instruction writes
-// 8 full 128-byte lines (acc -> +bias -> act -> bf16 -> ds_write_b64, chunk-XOR swizzled -> ds_read_b128 -> 16 B / lane).
+// Persistent bf16 GEMM, variant "q": same tile hand-over and LDS-staged asynchronous epilogue as gemm256p.hip, but the K
+// loop has TWO long phases per K-tile instead of four (4 barriers instead of 8, 32-MFMA clusters of 512 cycles):
+//   RA  16 ds_read_b128: B(cols 0-31), B(cols 32-63), A(rows 0-63); stage tile t+1: own A half (4 LDS-DMA) + B0 + B1
+//   MA  quadrants (0,0) and (0,1)
+//   RB   8 ds_read_b128: A(rows 64-127)
+//   MB  quadrants (1,1) and (1,0)
+// The wr == 1 half of the workgroup runs one barrier interval behind the wr == 0 half (intervals g0/g1: RA 0/1, MA 1/2,
+// RB 2/3, MB 3/4), so a SIMD's two waves alternate a 512-cycle MFMA cluster with the partner's LDS reads.
+// Staging ownership: an A half is read only by its own wave group, so that group alone stages it (4 pieces per wave)
+// right at its RA -- after its own last read of the slot (RB of the previous tile) in program order; the B halves of
+// tile t-1 were last read at RA(t-1) (waits at the start of intervals 1/2) and are refilled from interval 4/5 on.
+// Everything of tile t+1 is issued in interval 0/1 of tile t and waited for at the end of interval 3
+// (g0 after MB, g1 after RB): three intervals (~1500 cycles) of flight time.
 #include "common.h"
 
 namespace kemr {
@@ -29,7 +23,7 @@ constexpr int PEPI = 131072;     // offset of the epilogue area (8 waves x 2 KiB
 constexpr int PBIAS = PEPI + 16384;   // 2 x 1 KiB: fp32 bias of the current / next tile's 256 columns
 constexpr int PSMEM = PBIAS + 2048;
 
-__device__ __forceinline__ void glds16p(const void* gsrc, void* lds_wave_base) {
+__device__ __forceinline__ void glds16q(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
@@ -71,7 +65,7 @@ __device__ __forceinline__ void quad(f32x4 (&acc)[8][4], const bf16x8 (&af)[4][2
 }  // namespace
 
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256p_bf16_nt_kernel(const GemmParams p) {
+__global__ __launch_bounds__(512, 2) void gemm256q_bf16_nt_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -93,37 +87,42 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_nt_kernel(const GemmPara
         col0 = (L - tm * tiles_n) << 8;
     };
 
-    // staging addresses = wave-uniform tile base (SGPRs) + a per-lane 32-bit byte offset that never changes
+    // staging addresses = wave-uniform tile base (SGPRs) + a per-lane 32-bit byte offset that never changes.
+    // A: the wave stages pieces 4*(wid&3) .. +3 of ITS group's half; B: pieces 2*wid, 2*wid+1 of both halves.
     const int srow = lane >> 3, schunk = lane & 7;
+    unsigned a_lane[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = ((wid & 3) * 4 + j) * 8 + srow;
+        a_lane[j] = (unsigned)(r * p.lda + ((schunk ^ ((r >> 1) & 7)) << 3)) * 2u;
+    }
     const int r0 = wid * 16 + srow, r1 = r0 + 8;
-    const unsigned a_lane0 = (unsigned)(r0 * p.lda + ((schunk ^ ((r0 >> 1) & 7)) << 3)) * 2u;
-    const unsigned a_lane1 = (unsigned)(r1 * p.lda + ((schunk ^ ((r1 >> 1) & 7)) << 3)) * 2u;
     const unsigned w_lane0 = (unsigned)(r0 * p.ldw + ((schunk ^ ((r0 >> 1) & 7)) << 3)) * 2u;
     const unsigned w_lane1 = (unsigned)(r1 * p.ldw + ((schunk ^ ((r1 >> 1) & 7)) << 3)) * 2u;
     const size_t a_half = (size_t)256 * p.lda, w_half = (size_t)256 * p.ldw;      // bytes between the two half-tiles
-    char* const stage_base = smem + wid * 2048;
 
     const char *a_tile, *w_tile;                        // wave-uniform
     auto set_src = [&](int row0, int col0) {
-        a_tile = (const char*)p.A + (size_t)row0 * p.lda * 2;
+        a_tile = (const char*)p.A + (size_t)row0 * p.lda * 2 + wr * a_half;      // this group's A half
         w_tile = (const char*)p.W + (size_t)col0 * p.ldw * 2;
     };
-    auto stage_a = [&](int half, int tau) {
-        char* dst = stage_base + (tau & 1) * PBUF + half * PHALF;
-        const char* src = a_tile + half * a_half + tau * 128;
-        glds16p(src + a_lane0, dst);
-        glds16p(src + a_lane1, dst + 1024);
+    auto stage_a_own = [&](int tau) {                   // 4 LDS-DMA: the whole A half of this wave group
+        char* dst = smem + (tau & 1) * PBUF + wr * PHALF + (wid & 3) * 4096;
+        const char* src = a_tile + tau * 128;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16q(src + a_lane[j], dst + j * 1024);
     };
     auto stage_w = [&](int half, int tau) {
-        char* dst = stage_base + (tau & 1) * PBUF + (2 + half) * PHALF;
+        char* dst = smem + wid * 2048 + (tau & 1) * PBUF + (2 + half) * PHALF;
         const char* src = w_tile + half * w_half + tau * 128;
-        glds16p(src + w_lane0, dst);
-        glds16p(src + w_lane1, dst + 1024);
+        glds16q(src + w_lane0, dst);
+        glds16q(src + w_lane1, dst + 1024);
     };
+    auto stage_tile = [&](int tau) { stage_a_own(tau); stage_w(0, tau); stage_w(1, tau); };   // 8 LDS-DMA
     auto prologue = [&](int col0_, int parity) {   // K-tiles 0 and 1 complete: 16 LDS-DMA per lane (nt >= 2)
-        if (wid == 0 && p.bias) glds16p(p.bias + col0_ + lane * 4, smem + PBIAS + parity * 1024);
-        stage_a(0, 0); stage_a(1, 0); stage_w(0, 0); stage_w(1, 0);
-        stage_w(0, 1); stage_w(1, 1); stage_a(0, 1); stage_a(1, 1);
+        if (wid == 0 && p.bias) glds16q(p.bias + col0_ + lane * 4, smem + PBIAS + parity * 1024);
+        stage_tile(0);
+        stage_tile(1);
     };
 
     const int lrow = lane & 15, lq = lane >> 4;
@@ -180,54 +179,40 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_nt_kernel(const GemmPara
         for (int t = 0; t < nt; ++t) {
             const char* sa = smem + (t & 1) * PBUF + a_off;
             const char* sb = smem + (t & 1) * PBUF + b_off;
-            // K-tile 1 came with the prologue; the stores of the previous tile are older than everything staged in this
-            // loop but younger than K-tile 1, so the wait that closes K-tile 0 may leave them (and B0(2)) in flight
-            const bool more1 = t + 1 < nt && t > 0, more2 = t + 2 < nt;
+            // ---- RA
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 w0[ni][0] = *(const bf16x8*)(sb + ni * 2048 + co0);
                 w0[ni][1] = *(const bf16x8*)(sb + ni * 2048 + co1);
+                w1[ni][0] = *(const bf16x8*)(sb + 4096 + ni * 2048 + co0);
+                w1[ni][1] = *(const bf16x8*)(sb + 4096 + ni * 2048 + co1);
             }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 af[mi][0] = *(const bf16x8*)(sa + mi * 2048 + co0);
                 af[mi][1] = *(const bf16x8*)(sa + mi * 2048 + co1);
             }
-            if (more1) stage_w(1, t + 1);
+            if (t > 0 && t + 1 < nt) stage_tile(t + 1);          // K-tile 1 came with the hand-over prologue
             __builtin_amdgcn_s_barrier();
+            // ---- MA
             quad<0, 0>(acc, af, w0);
-            __builtin_amdgcn_s_barrier();
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                w1[ni][0] = *(const bf16x8*)(sb + 4096 + ni * 2048 + co0);
-                w1[ni][1] = *(const bf16x8*)(sb + 4096 + ni * 2048 + co1);
-            }
-            if (more1) stage_a(0, t + 1);
-            __builtin_amdgcn_s_barrier();
             quad<0, 1>(acc, af, w1);
             __builtin_amdgcn_s_barrier();
+            // ---- RB
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 af[mi][0] = *(const bf16x8*)(sa + 8192 + mi * 2048 + co0);
                 af[mi][1] = *(const bf16x8*)(sa + 8192 + mi * 2048 + co1);
             }
-            if (more1) stage_a(1, t + 1);
-            __builtin_amdgcn_s_barrier();
-            quad<1, 1>(acc, af, w1);
-            __builtin_amdgcn_s_barrier();
-            if (more2) stage_w(0, t + 2);
-            auto close_tile = [&]() {
+            auto close_tile = [&]() {      // tile t+1 landed; only the previous tile's stores may still fly (t == 0)
                 if (p.dbg & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if ((t == 0 || ((p.dbg & 8) && t < 6)) && had_stores) {   // dbg 8: TIMING ONLY (wrong results): stores may fly 6 K-tiles
-                    if (more2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                } else {
-                    if (more2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
+                if (t == 0 && had_stores) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             };
             if (wr == 1) close_tile();
             __builtin_amdgcn_s_barrier();
+            // ---- MB
+            quad<1, 1>(acc, af, w1);
             quad<1, 0>(acc, af, w0);
             if (wr == 0) close_tile();
             __builtin_amdgcn_s_barrier();
@@ -278,8 +263,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_nt_kernel(const GemmPara
 }
 
 template <int EPI>
-static int launch256p(const GemmParams& p, hipStream_t stream) {
-    auto kern = gemm256p_bf16_nt_kernel<EPI>;
+static int launch256q(const GemmParams& p, hipStream_t stream) {
+    auto kern = gemm256q_bf16_nt_kernel<EPI>;
     static bool attr_done = false;
     static int num_cu = 0;
     if (!attr_done) {
@@ -295,15 +280,15 @@ static int launch256p(const GemmParams& p, hipStream_t stream) {
     q.dbg = g_gemm_dbg;
     ProfScope prof(PROF_GEMM, stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), PSMEM, stream, q);
-    KEMR_CHECK_LAUNCH("gemm256p_bf16_nt_kernel");
+    KEMR_CHECK_LAUNCH("gemm256q_bf16_nt_kernel");
     return KEMR_OK;
 }
 
 // C must have ceil256(M) rows: rows in [M, ceil256(M)) are written (with values computed from A's pad rows).
-int launch_gemm256p(const GemmParams& p, int epi, hipStream_t stream) {
+int launch_gemm256q(const GemmParams& p, int epi, hipStream_t stream) {
     switch (epi) {
-        case EPI_BIAS_BF16:       return launch256p<EPI_BIAS_BF16>(p, stream);
-        case EPI_BIAS_QGELU_BF16: return launch256p<EPI_BIAS_QGELU_BF16>(p, stream);
+        case EPI_BIAS_BF16:       return launch256q<EPI_BIAS_BF16>(p, stream);
+        case EPI_BIAS_QGELU_BF16: return launch256q<EPI_BIAS_QGELU_BF16>(p, stream);
     }
     KEMR_FAIL(KEMR_ERR_INVALID, "gemm256p: epilogue %d is not a bf16-store epilogue", epi);
 }

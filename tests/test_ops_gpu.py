@@ -15,7 +15,7 @@ def _bf16_round(x):
 
 @pytest.mark.parametrize("m,n,k", [(257, 256, 256), (300, 768, 256), (1000, 1024, 1024), (514, 256, 1024), (63 * 257, 1024, 1024)])
 @pytest.mark.parametrize("epi", [_lib.EPI_BIAS_BF16, _lib.EPI_BIAS_QGELU_BF16, _lib.EPI_BIAS_RESID_F32])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 def test_gemm_epilogues(device, m, n, k, epi, variant):
     engine.set_gemm_variant(variant)      # 1: 128x128 tiles, 2: 256x256 tiles (every N here is a multiple of 256)
     try:
@@ -50,7 +50,7 @@ def _gemm_epilogue_case(device, m, n, k, epi):
     # bf16 epilogues: rows in [m, m_alloc) are scratch (the persistent kernel stores whole tiles)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 def test_gemm_identity_asymmetric(device, variant):
     """A = I against an asymmetric W catches transposed / permuted fragment maps (cdna guide section 3)."""
     k = n = 512
@@ -66,7 +66,8 @@ def test_gemm_identity_asymmetric(device, variant):
     assert torch.equal(out.float().cpu(), w.T.contiguous().to(torch.bfloat16).float())
 
 
-def test_gemm_persistent_many_tiles_per_cu(device):
+@pytest.mark.parametrize("variant", [4, 5])
+def test_gemm_persistent_many_tiles_per_cu(device, variant):
     """Persistent kernel: > 256 tiles so that every workgroup walks several tiles (hand-over path), ragged M, with and
     without bias, both bf16 epilogues."""
     g = torch.Generator().manual_seed(11)
@@ -76,7 +77,7 @@ def test_gemm_persistent_many_tiles_per_cu(device):
     w = (torch.randn(n, k, generator=g) * k ** -0.5).to(torch.bfloat16)
     bias = torch.randn(n, generator=g)
     ref = a.float()[:m] @ w.float().T
-    engine.set_gemm_variant(4)
+    engine.set_gemm_variant(variant)
     try:
         for epi, b in ((_lib.EPI_BIAS_BF16, None), (_lib.EPI_BIAS_BF16, bias), (_lib.EPI_BIAS_QGELU_BF16, bias)):
             r = ref + (b if b is not None else 0)

@@ -6,8 +6,8 @@ import torch
 from knowledge_enhanced_multimodal_retrieval_amd import engine
 dev = torch.device("cuda:0")
 B = 255
-shapes = [("v.qkv", B * 257, 3072, 1024, 0), ("v.out", B * 257, 1024, 1024, 2), ("v.fc1", B * 257, 4096, 1024, 1),
-          ("v.fc2", B * 257, 1024, 4096, 2), ("sq4096", 4096, 4096, 4096, 0)]
+shapes = [("v.qkv", B * 257, 3072, 1024, 0), ("v.out", B * 257, 1024, 1024, 0), ("v.fc1", B * 257, 4096, 1024, 1),
+          ("v.fc2", B * 257, 1024, 4096, 0), ("sq4096", 4096, 4096, 4096, 0)]
 g = torch.Generator(device=dev).manual_seed(0)
 for name, m, n, k, epi in shapes:
     ma = (m + 255) // 256 * 256
@@ -17,7 +17,7 @@ for name, m, n, k, epi in shapes:
     c = torch.zeros(ma, n, dtype=torch.float32 if epi == 2 else torch.bfloat16, device=dev)
     out = {}
     for rnd in range(4):
-        for v in (2, 3, 2 | 256, 3 | 256):
+        for v in (4, 4 | (8 << 8), 4 | (1 << 8)):
             engine.set_gemm_variant(v)
             for _ in range(2):
                 engine.op_gemm(a, w, bias, m, epi, c=c)
@@ -29,5 +29,5 @@ for name, m, n, k, epi in shapes:
             e1.record()
             torch.cuda.synchronize()
             out.setdefault(v, []).append(e0.elapsed_time(e1) / 10 * 1e3)
-    print(name, {("v%d%s" % (v & 255, "_nostore" if v >> 8 else "")): round(sorted(t)[len(t) // 2], 1) for v, t in out.items()}, flush=True)
+    print(name, {("v%d_dbg%d" % (v & 255, v >> 8)): round(sorted(t)[len(t) // 2], 1) for v, t in out.items()}, flush=True)
 engine.set_gemm_variant(0)
