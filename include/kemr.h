@@ -173,6 +173,15 @@ int kemr_rank_dense(const float* scores_dev, int nq, int ng, int64_t ld, const i
 int kemr_linear_head(const float* t2i_dev, const float* t2t_dev, int64_t n, const float* w0_dev, const float* b0_dev,
                      const float* w1_dev, float b1, int hidden, float* out_dev, void* stream);
 
+/* Pair stage of the learned "cross_attention" fusion head in eval mode (reference src/clip/model/fusion_model.py:51-133).
+ * Inputs are per-query / per-candidate quantities the host precomputes with the dense kernels (see fusion_model.py of the
+ * build): st_x fp32 [heads][n_c][n_q] scaled attention scores (x = image / target key), p_x fp32 [n_c][heads][hid1] =
+ * W1.Wo[:,head].V_x, c0 = W1.bo + b1 [hid1], w2t = W2^T [hid1][hid2], b2 [hid2], w3 [hid2], b3.
+ * out_t fp32 [n_c][n_q] = 0.5 * tanh(MLP(softmax-mixed context))  (transposed score matrix). */
+int kemr_cross_attention_pairs(const float* st_i_dev, const float* st_t_dev, const float* p_i_dev, const float* p_t_dev,
+                               const float* c0_dev, const float* w2t_dev, const float* b2_dev, const float* w3_dev, float b3,
+                               int heads, int n_q, int n_c, int hid1, int hid2, float* out_t_dev, void* stream);
+
 /* Optional per-kernel-class timing with hipEvents recorded on the launch stream (bench.py's roofline line).
  * Classes: 0 GEMM, 1 LayerNorm, 2 attention, 3 embed/tail, 4 similarity tile kernel.  Not thread-safe;
  * profile_end synchronises the device.  Off by default: no events are recorded on the normal path. */

@@ -111,9 +111,89 @@ __global__ __launch_bounds__(256) void linear_head_kernel(const float* __restric
     }
 }
 
+// Learned "cross_attention" fusion head (reference fusion_model.py:51-133, eval mode), pair stage.
+// The reference runs, for EVERY (query n, candidate m) pair, an 8-head attention of one query over two keys
+// (image / target), the D x D output projection and a D->256->64->1 MLP: O(N*M*D^2).  All of it except the two
+// softmax weights per head is linear in per-candidate quantities, so the host precomputes, per candidate and head,
+//   P_x[m][h][:] = W1 . Wo[:, head h] . V_x[m][h][:]   (x = image / target; 256 floats)
+// and this kernel only does, per pair: 2-way softmax of the 2*H scaled scores, hidden1 = relu(c0 + sum_h w_i P_i + w_t P_t)
+// (H*2 FMAs per hidden unit), the 256->64 layer fused on the fly, the 64->1 layer and 0.5*tanh.  ~21 kFLOP per pair
+// instead of ~1.6 MFLOP.  One workgroup per candidate m (its P rows, W2^T in LDS: broadcast reads), threads over n.
+// scores come transposed, st[x][h][m][n], so that threads (consecutive n) read and write coalesced.
+template <int H>
+__global__ __launch_bounds__(256) void cross_attn_pair_kernel(const float* __restrict__ st_i, const float* __restrict__ st_t,
+                                                              const float* __restrict__ p_i, const float* __restrict__ p_t,
+                                                              const float* __restrict__ c0, const float* __restrict__ w2t,
+                                                              const float* __restrict__ b2, const float* __restrict__ w3,
+                                                              float b3, int n_q, int n_c, int hid1, int hid2,
+                                                              float* __restrict__ out_t /* [n_c][n_q] */) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sP = (float*)smem;                       // [2][H][hid1]
+    float* sW2 = sP + 2 * H * hid1;                 // [hid1][hid2]  (W2 transposed)
+    float* sC0 = sW2 + hid1 * hid2;                 // [hid1]
+    const int m = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < H * hid1; i += 256) {
+        sP[i] = p_i[(size_t)m * H * hid1 + i];
+        sP[H * hid1 + i] = p_t[(size_t)m * H * hid1 + i];
+    }
+    for (int i = tid; i < hid1 * hid2; i += 256) sW2[i] = w2t[i];
+    for (int i = tid; i < hid1; i += 256) sC0[i] = c0[i];
+    __syncthreads();
+    const size_t plane = (size_t)n_c * n_q;
+    for (int n = tid; n < n_q; n += 256) {
+        float wi[H], wt[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float a = st_i[h * plane + (size_t)m * n_q + n], b = st_t[h * plane + (size_t)m * n_q + n];
+            const float mx = fmaxf(a, b);
+            const float ea = __expf(a - mx), eb = __expf(b - mx);
+            const float inv = 1.0f / (ea + eb);
+            wi[h] = ea * inv;
+            wt[h] = eb * inv;
+        }
+        float acc[64];                               // hid2 <= 64
+#pragma unroll
+        for (int k = 0; k < 64; ++k) acc[k] = 0.f;
+        for (int j = 0; j < hid1; ++j) {
+            float hsum = sC0[j];
+#pragma unroll
+            for (int h = 0; h < H; ++h) hsum = fmaf(wi[h], sP[h * hid1 + j], fmaf(wt[h], sP[(H + h) * hid1 + j], hsum));
+            hsum = fmaxf(hsum, 0.f);
+            const float* w2row = sW2 + j * hid2;
+#pragma unroll
+            for (int k = 0; k < 64; ++k)
+                if (k < hid2) acc[k] = fmaf(hsum, w2row[k], acc[k]);
+        }
+        float o = b3;
+#pragma unroll
+        for (int k = 0; k < 64; ++k)
+            if (k < hid2) o = fmaf(fmaxf(acc[k] + b2[k], 0.f), w3[k], o);
+        out_t[(size_t)m * n_q + n] = 0.5f * tanhf(o);
+    }
+}
+
 }  // namespace kemr
 
 using namespace kemr;
+
+extern "C" int kemr_cross_attention_pairs(const float* st_i_dev, const float* st_t_dev, const float* p_i_dev,
+                                          const float* p_t_dev, const float* c0_dev, const float* w2t_dev,
+                                          const float* b2_dev, const float* w3_dev, float b3, int heads, int n_q, int n_c,
+                                          int hid1, int hid2, float* out_t_dev, void* stream) {
+    if (n_q == 0 || n_c == 0) return KEMR_OK;
+    if (!st_i_dev || !st_t_dev || !p_i_dev || !p_t_dev || !c0_dev || !w2t_dev || !b2_dev || !w3_dev || !out_t_dev)
+        KEMR_FAIL(KEMR_ERR_INVALID, "cross_attention_pairs: null argument");
+    if (heads != 8) KEMR_FAIL(KEMR_ERR_INVALID, "cross_attention_pairs: the reference head has 8 attention heads (got %d)", heads);
+    if (hid2 < 1 || hid2 > 64 || hid1 < 1 || n_q < 0 || n_c < 0) KEMR_FAIL(KEMR_ERR_INVALID, "cross_attention_pairs: bad sizes");
+    const size_t smem = ((size_t)2 * heads * hid1 + (size_t)hid1 * hid2 + hid1) * 4;
+    if (smem > 160 * 1024) KEMR_FAIL(KEMR_ERR_INVALID, "cross_attention_pairs: hidden sizes do not fit LDS");
+    auto kern = cross_attn_pair_kernel<8>;
+    KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, dim3(n_c), dim3(256), smem, (hipStream_t)stream, st_i_dev, st_t_dev, p_i_dev, p_t_dev, c0_dev,
+                       w2t_dev, b2_dev, w3_dev, b3, n_q, n_c, hid1, hid2, out_t_dev);
+    KEMR_CHECK_LAUNCH("cross_attn_pair_kernel");
+    return KEMR_OK;
+}
 
 extern "C" int kemr_linear_head(const float* t2i_dev, const float* t2t_dev, int64_t n, const float* w0_dev,
                                 const float* b0_dev, const float* w1_dev, float b1, int hidden, float* out_dev,

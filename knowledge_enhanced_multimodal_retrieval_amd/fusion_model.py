@@ -12,10 +12,13 @@ inactive) and maps onto the fused similarity kernel:
   with the same kernel) instead of to the M candidates; then one weighted contraction as above.
 * linear: MLP(2->128->1) of every (t2i, t2t) pair -- needs both dense matrices; ``kemr_linear_head`` applies the MLP
   element-wise on the GPU.
-* cross_attention: per-pair multi-head attention over two keys + a 3-layer MLP, O(N*M*D^2) -- NOT built yet
-  (DESIGN.md "not yet built"); ``forward`` raises ``NotImplementedError`` for it.
+* cross_attention: per-pair multi-head attention of one query over two keys + out-projection + a 3-layer MLP,
+  O(N*M*D^2) in the reference.  Everything but the per-head 2-way softmax weights is linear in per-candidate
+  quantities, so the projections are folded per candidate (``P = W1.Wo[:,head].V``, small dense contractions with
+  the similarity kernel) and ``kemr_cross_attention_pairs`` does ~21 kFLOP per pair instead of ~1.6 MFLOP.
 
-``rank()`` gives ranks / top-k without ever forming the [N,M] matrix (all heads except linear / cross_attention).
+``rank()`` gives ranks / top-k without ever forming the [N,M] matrix for the gated family and bilinear; linear and
+cross_attention produce the dense matrix on the GPU and rank it with ``kemr_rank_dense``.
 """
 from __future__ import annotations
 
@@ -72,7 +75,7 @@ class BilinearFusionHead(nn.Module):
 
 
 class CrossAttentionFusionHead(nn.Module):
-    """Parameter container only (checkpoints load); scoring is not built yet."""
+    """Parameter container (reference checkpoints load); scored by ``FusionModel._cross_attention``."""
 
     def __init__(self, embed_dim: int = 768, num_heads: int = 8, hidden_dim: int = 256):
         super().__init__()
@@ -139,11 +142,74 @@ class FusionModel(nn.Module):
             return wq, [img, tgt], [a, 1.0 - a], None
         raise NotImplementedError
 
+    @staticmethod
+    def _linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x @ weight.T (+ bias) through the fp32x3 dense similarity kernel (x [R,K], weight [O,K])."""
+        xp = engine.build_panel([x.float().contiguous()], _lib.SIDE_QUERY, 3)
+        wp = engine.build_panel([weight.detach().float().contiguous()], _lib.SIDE_GALLERY, 3)
+        y = engine.scores_dense(xp, wp)
+        return y if bias is None else y + bias.detach().float()
+
+    @torch.no_grad()
+    def _cross_attention(self, q, img, tgt) -> torch.Tensor:
+        """Eval-mode CrossAttentionFusionHead.forward (reference fusion_model.py:83-133) -> [N, M] fp32."""
+        h = self.fusion_head.to(q.device).eval()
+        lin = self._linear
+        N, D = q.shape
+        M = img.shape[0]
+        H = h.cross_attn.num_heads
+        hd = D // H
+        Wqkv, bqkv = h.cross_attn.in_proj_weight.detach(), h.cross_attn.in_proj_bias.detach()
+        qp = lin(q, h.query_proj.weight, h.query_proj.bias)
+        ip = lin(img, h.image_proj.weight, h.image_proj.bias)
+        tp = lin(tgt, h.target_proj.weight, h.target_proj.bias)
+        Q = lin(qp, Wqkv[:D], bqkv[:D]) * (hd ** -0.5)
+        Ki, Kt = lin(ip, Wqkv[D:2 * D], bqkv[D:2 * D]), lin(tp, Wqkv[D:2 * D], bqkv[D:2 * D])
+        Vi, Vt = lin(ip, Wqkv[2 * D:], bqkv[2 * D:]), lin(tp, Wqkv[2 * D:], bqkv[2 * D:])
+        Wo, bo = h.cross_attn.out_proj.weight.detach().float(), h.cross_attn.out_proj.bias.detach().float()
+        W1, b1 = h.score_mlp[0].weight.detach().float(), h.score_mlp[0].bias.detach().float()
+        W2, b2 = h.score_mlp[3].weight.detach().float(), h.score_mlp[3].bias.detach().float()
+        W3, b3 = h.score_mlp[6].weight.detach().float().reshape(-1), float(h.score_mlp[6].bias.detach())
+        hid1, hid2 = W1.shape[0], W2.shape[0]
+        Pi = torch.empty((M, H, hid1), dtype=torch.float32, device=q.device)
+        Pt = torch.empty_like(Pi)
+        for hh in range(H):
+            sl = slice(hh * hd, (hh + 1) * hd)
+            G = lin(W1, Wo[:, sl].t().contiguous())                     # [hid1, hd] = W1 . Wo[:, head]
+            Pi[:, hh] = lin(Vi[:, sl].contiguous(), G)
+            Pt[:, hh] = lin(Vt[:, sl].contiguous(), G)
+        c0 = (lin(bo[None, :], W1)[0] + b1).contiguous()
+        w2t = W2.t().contiguous()
+        out = torch.empty((N, M), dtype=torch.float32, device=q.device)
+        step = max(1, min(N, (256 << 20) // max(1, 2 * H * M * 4)))   # bound the transposed score planes to ~256 MB
+        L = _lib.lib()
+        for s0 in range(0, N, step):
+            Qc = Q[s0:s0 + step]
+            nc = Qc.shape[0]
+            sti = torch.empty((H, M, nc), dtype=torch.float32, device=q.device)
+            stt = torch.empty_like(sti)
+            for hh in range(H):
+                sl = slice(hh * hd, (hh + 1) * hd)
+                qh = Qc[:, sl].contiguous()
+                sti[hh] = lin(Ki[:, sl].contiguous(), qh)               # [M, nc]: candidates x queries (transposed)
+                stt[hh] = lin(Kt[:, sl].contiguous(), qh)
+            out_t = torch.empty((M, nc), dtype=torch.float32, device=q.device)
+            with torch.cuda.device(q.device):
+                _lib.check(L.kemr_cross_attention_pairs(
+                    C.c_void_p(sti.data_ptr()), C.c_void_p(stt.data_ptr()), C.c_void_p(Pi.data_ptr()), C.c_void_p(Pt.data_ptr()),
+                    C.c_void_p(c0.data_ptr()), C.c_void_p(w2t.data_ptr()), C.c_void_p(b2.contiguous().data_ptr()),
+                    C.c_void_p(W3.contiguous().data_ptr()), b3, H, nc, M, hid1, hid2, C.c_void_p(out_t.data_ptr()),
+                    C.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)), "cross_attention_pairs")
+            out[s0:s0 + nc] = out_t.t()
+        return out
+
     @torch.no_grad()
     def forward(self, query_embed, image_embed, target_embed) -> torch.Tensor:
         """-> dense [N, M] fused scores (fp32, on the GPU)."""
         if self.fusion_type == "cross_attention":
-            raise NotImplementedError("cross_attention fusion scoring is not built yet on the HIP path (DESIGN.md)")
+            q = ranking.to_device_f32(query_embed)
+            return self._cross_attention(q, ranking.to_device_f32(image_embed, q.device),
+                                         ranking.to_device_f32(target_embed, q.device))
         if self.fusion_type == "linear":
             q = ranking.to_device_f32(query_embed)
             img, tgt = ranking.to_device_f32(image_embed, q.device), ranking.to_device_f32(target_embed, q.device)
@@ -169,9 +235,7 @@ class FusionModel(nn.Module):
     def rank(self, query_embed, image_embed, target_embed, k: int = 10, gt_idx="diag"
              ) -> Tuple[Optional[torch.Tensor], torch.Tensor, torch.Tensor]:
         """Ranks / top-k under this head without the [N, M] matrix (linear: dense matrix, then a streaming rank)."""
-        if self.fusion_type == "linear":
+        if self.fusion_type in ("linear", "cross_attention"):
             return ranking.ranks_of_matrix(self.forward(query_embed, image_embed, target_embed), k=k, gt_idx=gt_idx)
-        if self.fusion_type == "cross_attention":
-            raise NotImplementedError("cross_attention fusion scoring is not built yet on the HIP path (DESIGN.md)")
         qs, gs, weights, gates = self._parts(query_embed, image_embed, target_embed)
         return ranking.ranks_and_topk(qs, gs, weights=weights, row_gate=gates, k=k, gt_idx=gt_idx)

@@ -80,7 +80,7 @@ def test_config2_fused_scoring_cli(device, tmp_path):
     assert json.loads(out.read_text())["checkpoint"] == str(ck)
 
 
-@pytest.mark.parametrize("ft", ["linear", "gated", "simple_gated", "simple_gated_with_bias", "bilinear"])
+@pytest.mark.parametrize("ft", ["linear", "gated", "simple_gated", "simple_gated_with_bias", "bilinear", "cross_attention"])
 def test_fusion_heads_match_reference_golden(device, golden_dir, ft):
     from src.clip.models import FusionModel
     z = np.load(os.path.join(golden_dir, "fusion_heads.npz"))
@@ -106,11 +106,22 @@ def test_fusion_heads_match_reference_golden(device, golden_dir, ft):
     assert np.array_equal(top_i.cpu().numpy()[:, 0], want.argmax(axis=1))
 
 
-def test_cross_attention_head_is_an_explicit_gap(device):
+def test_cross_attention_head_at_clip_width(device):
+    """D = 768 (head dim 96, not a multiple of 64) against the float64 oracle restatement of the reference head."""
     from src.clip.models import FusionModel
-    fm = FusionModel(torch.nn.Linear(1, 1), fusion_type="cross_attention", embed_dim=64)
-    with pytest.raises(NotImplementedError):
-        fm(np.zeros((2, 64), np.float32), np.zeros((3, 64), np.float32), np.zeros((3, 64), np.float32))
+    g = torch.Generator().manual_seed(3)
+    D, N, M = 768, 37, 53
+    fm = FusionModel(torch.nn.Linear(1, 1), fusion_type="cross_attention", embed_dim=D)
+    with torch.no_grad():
+        for p_ in fm.fusion_head.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.05 if p_.dim() > 1 else 0.1))
+    q = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=-1).numpy()
+    im = torch.nn.functional.normalize(torch.randn(M, D, generator=g), dim=-1).numpy()
+    tg = torch.nn.functional.normalize(torch.randn(M, D, generator=g), dim=-1).numpy()
+    sd = {k: v.numpy() for k, v in fm.fusion_head.state_dict().items()}
+    want = fusion_ref.head_scores("cross_attention", sd, q, im, tg)
+    got = fm.to(device)(q, im, tg).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-3, atol=2e-5)
     with pytest.raises(ValueError):
         FusionModel(torch.nn.Linear(1, 1), fusion_type="bogus")
 
