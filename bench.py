@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=255, help="gallery items per rank per step")
     ap.add_argument("--model", default="ViT-L/14")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16-res16"],
+                    help="bf16 operands with an fp32 (default) or bf16 residual stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sim", action="store_true")
     args = ap.parse_args()
@@ -133,7 +135,7 @@ def main():
 
     arch = ARCHS[args.model]
     B = args.batch
-    eng = engine.ClipEngine(arch, dev)
+    eng = engine.ClipEngine(arch, dev, precision=args.precision)
     eng.load_state_dict(random_weights(arch, seed=0))
 
     g = torch.Generator().manual_seed(1234 + rank)
@@ -177,7 +179,7 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "CLIP ViT-L/14 zero-shot: 43k-gallery encode (1 image + query + target text per item, "
                                "224x224 / 77 tokens) + T2I top-10, BASELINE configs[1]",
-                   "model": args.model, "batch_per_gpu": B, "gallery": GALLERY, "parallelism": f"dp{world} (gallery sharded)"},
+                   "model": args.model, "residual_stream": "bf16" if args.precision == "bf16-res16" else "fp32", "batch_per_gpu": B, "gallery": GALLERY, "parallelism": f"dp{world} (gallery sharded)"},
         "images_per_s": B * world * args.steps / elapsed,
         "texts_per_s": 2 * B * world * args.steps / elapsed,
         "encode_tflops_per_gpu": flops_item_step * args.steps / elapsed / 1e12,

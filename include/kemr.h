@@ -44,7 +44,11 @@ typedef enum kemr_status {
 typedef enum kemr_dtype { KEMR_F32 = 0, KEMR_BF16 = 1, KEMR_I32 = 2 } kemr_dtype;
 
 /* compute precision of the encoder GEMMs (activations + weights); accumulation is always fp32 */
-typedef enum kemr_precision { KEMR_PREC_BF16 = 1 } kemr_precision;
+/* KEMR_PREC_BF16:       bf16 GEMM / attention operands, fp32 residual stream (closest to the reference's .float() model)
+ * KEMR_PREC_BF16_RES16: as above with the residual stream stored as bf16 between layers (what fp16/bf16 CLIP inference
+ *                       does everywhere); LayerNorm statistics and the residual add stay fp32.  8 instead of 12 bytes
+ *                       of HBM traffic per residual element and LayerNorm, and 14 instead of 16 workspace bytes. */
+typedef enum kemr_precision { KEMR_PREC_BF16 = 1, KEMR_PREC_BF16_RES16 = 2 } kemr_precision;
 
 typedef enum kemr_tower { KEMR_TOWER_VISION = 0, KEMR_TOWER_TEXT = 1 } kemr_tower;
 
@@ -210,6 +214,9 @@ int kemr_op_layernorm(const float* x_dev, const float* gamma_dev, const float* b
 /* fused residual form used inside the towers: x_f32 += delta_bf16 (written back), y_bf16 = LayerNorm(x) */
 int kemr_op_layernorm_resid(float* x_dev, const void* delta_dev, const float* gamma_dev, const float* beta_dev,
                             void* y_dev, int rows, int width, void* stream);
+/* general form: rows of x_dtype (KEMR_F32|KEMR_BF16); delta_dev may be NULL (then x is only read, unless y_dev == x_dev) */
+int kemr_op_layernorm_rows(void* x_dev, int x_dtype, const void* delta_dev, const float* gamma_dev, const float* beta_dev,
+                           void* y_dev, int rows, int width, int out_dtype, void* stream);
 /* qkv bf16 [batch*t, 3*width] (q pre-scaled by 1/8) -> out bf16 [batch*t, width] */
 int kemr_op_attention(const void* qkv_dev, void* out_dev, int batch, int t, int width, int causal, void* stream);
 

@@ -17,6 +17,8 @@ LIB_PATH = os.path.join(PKG_DIR, "libkemr.so")
 
 KEMR_F32, KEMR_BF16, KEMR_I32 = 0, 1, 2
 PREC_BF16 = 1
+PREC_BF16_RES16 = 2
+PRECISIONS = {"bf16": PREC_BF16, "bf16-res16": PREC_BF16_RES16}
 TOWER_VISION, TOWER_TEXT = 0, 1
 SIDE_QUERY, SIDE_GALLERY = 0, 1
 EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RESID_F32 = 0, 1, 2
@@ -58,6 +60,7 @@ SIGNATURES = {
     "kemr_op_gemm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "kemr_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "kemr_op_layernorm_resid": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "kemr_op_layernorm_rows": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "kemr_op_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
 }
 

@@ -66,6 +66,7 @@ struct kemr_model {
     char* arena = nullptr;                          // device weights
     size_t arena_bytes = 0;
     int grid = 0, patches = 0, kpad = 0;
+    int res_dtype = KEMR_F32;                       // storage type of the residual stream (KEMR_PREC_BF16_RES16: bf16)
     // vision
     TowerW vis;
     const bf16_t* conv_w = nullptr;
@@ -184,7 +185,8 @@ extern "C" int kemr_model_load_tensor(kemr_model* m, const char* name, const voi
 
 extern "C" int kemr_model_finalize(kemr_model* m, int precision) {
     if (!m) KEMR_FAIL(KEMR_ERR_INVALID, "finalize: null model");
-    if (precision != KEMR_PREC_BF16) KEMR_FAIL(KEMR_ERR_INVALID, "finalize: unsupported precision %d", precision);
+    if (precision != KEMR_PREC_BF16 && precision != KEMR_PREC_BF16_RES16)
+        KEMR_FAIL(KEMR_ERR_INVALID, "finalize: unsupported precision %d", precision);
     for (const auto& n : m->names)
         if (!m->tensors[n].loaded) KEMR_FAIL(KEMR_ERR_STATE, "finalize: missing key '%s' (strict load)", n.c_str());
 
@@ -265,6 +267,7 @@ extern "C" int kemr_model_finalize(kemr_model* m, int precision) {
     m->lnf_g = F("ln_final.weight"); m->lnf_b = F("ln_final.bias"); m->tproj = F("text_projection");
 
     for (auto& kv : m->tensors) { std::vector<float>().swap(kv.second.data); kv.second.loaded = false; }
+    m->res_dtype = precision == KEMR_PREC_BF16_RES16 ? KEMR_BF16 : KEMR_F32;
     m->finalized = true;
     return KEMR_OK;
 }
@@ -280,24 +283,29 @@ extern "C" int kemr_model_destroy(kemr_model* m) {
 namespace {
 
 struct Workspace {
-    float* x;       // [Mp, W] fp32 residual stream
+    void* x;        // [Mp, W] residual stream, fp32 or bf16 (x_dtype)
+    int x_dtype;
     bf16_t* h;      // [Mp, W] bf16: LayerNorm output / attention output (GEMM A operand)
     bf16_t* big;    // [Mp, 4W] bf16: qkv (ld 3W), MLP hidden (ld 4W), im2col patches
     bf16_t* delta;  // [Mp, W] bf16: output of the out-proj / fc2 GEMMs, added to x by the next LayerNorm (or the tail)
+    float* x32;     // [Mp, W] fp32 front-end rows of the vision tower (patch GEMM + cls, read by ln_pre): x itself for
+                    // an fp32 stream, else the (then still unused) h | delta pair, which is contiguous and as large
 };
 
-size_t ws_bytes(int width, int tokens, int batch) {
+size_t ws_bytes(int width, int tokens, int batch, int x_dtype) {
     const int64_t Mp = round_up((int64_t)batch * tokens, 256);
-    return (size_t)(round_up(Mp * width * 4, 256) + 2 * round_up(Mp * width * 2, 256) + round_up(Mp * width * 8, 256));
+    const int xb = x_dtype == KEMR_BF16 ? 2 : 4;
+    return (size_t)(round_up(Mp * width * xb, 256) + 2 * round_up(Mp * width * 2, 256) + round_up(Mp * width * 8, 256));
 }
 
-int carve(Workspace& w, void* base, size_t bytes, int width, int tokens, int batch) {
-    const size_t need = ws_bytes(width, tokens, batch);
+int carve(Workspace& w, void* base, size_t bytes, int width, int tokens, int batch, int x_dtype) {
+    const size_t need = ws_bytes(width, tokens, batch, x_dtype);
     if (!base || bytes < need) KEMR_FAIL(KEMR_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", bytes, need);
     if ((uintptr_t)base % 256) KEMR_FAIL(KEMR_ERR_WORKSPACE, "workspace must be 256-byte aligned");
     const int64_t Mp = round_up((int64_t)batch * tokens, 256);
     char* p = (char*)base;
-    w.x = (float*)p; p += round_up(Mp * width * 4, 256);
+    w.x = p; w.x_dtype = x_dtype; p += round_up(Mp * width * (x_dtype == KEMR_BF16 ? 2 : 4), 256);
+    w.x32 = x_dtype == KEMR_BF16 ? (float*)p : (float*)w.x;
     w.h = (bf16_t*)p; p += round_up(Mp * width * 2, 256);
     w.delta = (bf16_t*)p; p += round_up(Mp * width * 2, 256);
     w.big = (bf16_t*)p;
@@ -313,7 +321,7 @@ int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, hipSt
     const bf16_t* carry = nullptr;
     for (int l = 0; l < t.layers; ++l) {
         const LayerW& L = t.layer[l];
-        KEMR_TRY(launch_layernorm(w.x, carry, L.ln1_g, L.ln1_b, w.h, M, W, KEMR_BF16, s));
+        KEMR_TRY(launch_layernorm(w.x, w.x_dtype, carry, L.ln1_g, L.ln1_b, w.h, M, W, KEMR_BF16, s));
         GemmParams g{};
         g.M = M;
         g.c_rows_padded = 1;       // every workspace buffer has ceil256(M) rows
@@ -322,7 +330,7 @@ int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, hipSt
         KEMR_TRY(launch_attention(w.big, w.h, batch, t.tokens, W, causal, s));
         g.A = w.h; g.lda = W; g.W = L.wo; g.ldw = W; g.bias = L.bo; g.C = w.delta; g.ldc = W; g.N = W; g.K = W;
         KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
-        KEMR_TRY(launch_layernorm(w.x, w.delta, L.ln2_g, L.ln2_b, w.h, M, W, KEMR_BF16, s));
+        KEMR_TRY(launch_layernorm(w.x, w.x_dtype, w.delta, L.ln2_g, L.ln2_b, w.h, M, W, KEMR_BF16, s));
         g.A = w.h; g.lda = W; g.W = L.w1; g.ldw = W; g.bias = L.b1; g.C = w.big; g.ldc = 4 * W; g.N = 4 * W; g.K = W;
         KEMR_TRY(launch_gemm(g, EPI_BIAS_QGELU_BF16, s));
         g.A = w.big; g.lda = 4 * W; g.W = L.w2; g.ldw = 4 * W; g.bias = L.b2; g.C = w.delta; g.ldc = W; g.N = W; g.K = 4 * W;
@@ -337,8 +345,8 @@ int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, hipSt
 
 extern "C" size_t kemr_workspace_bytes(const kemr_model* m, int tower, int batch) {
     if (!m || batch <= 0) return 0;
-    if (tower == KEMR_TOWER_VISION) return ws_bytes(m->cfg.v_width, m->patches + 1, batch);
-    if (tower == KEMR_TOWER_TEXT) return ws_bytes(m->cfg.t_width, m->cfg.ctx, batch);
+    if (tower == KEMR_TOWER_VISION) return ws_bytes(m->cfg.v_width, m->patches + 1, batch, m->res_dtype);
+    if (tower == KEMR_TOWER_TEXT) return ws_bytes(m->cfg.t_width, m->cfg.ctx, batch, m->res_dtype);
     return 0;
 }
 
@@ -351,17 +359,17 @@ extern "C" int kemr_encode_image(kemr_model* m, const float* pixels_dev, int bat
     hipStream_t s = (hipStream_t)stream;
     const int W = m->cfg.v_width, T = m->patches + 1;
     Workspace w;
-    KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, T, batch));
+    KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, T, batch, m->res_dtype));
     KEMR_TRY(launch_im2col(pixels_dev, w.big, batch, m->cfg.image_size, m->cfg.patch, m->kpad, s));
     GemmParams g{};
-    g.A = w.big; g.lda = m->kpad; g.W = m->conv_w; g.ldw = m->kpad; g.bias = nullptr; g.C = w.x; g.ldc = W;
+    g.A = w.big; g.lda = m->kpad; g.W = m->conv_w; g.ldw = m->kpad; g.bias = nullptr; g.C = w.x32; g.ldc = W;
     g.pos = m->vpos; g.patches = m->patches; g.M = batch * m->patches; g.N = W; g.K = m->kpad;
     KEMR_TRY(launch_gemm(g, EPI_PATCH_F32, s));
-    KEMR_TRY(launch_cls_rows(w.x, m->cls, m->vpos, batch, T, W, s));
-    KEMR_TRY(launch_layernorm(w.x, nullptr, m->lnpre_g, m->lnpre_b, w.x, batch * T, W, KEMR_F32, s));
+    KEMR_TRY(launch_cls_rows(w.x32, m->cls, m->vpos, batch, T, W, s));
+    KEMR_TRY(launch_layernorm(w.x32, KEMR_F32, nullptr, m->lnpre_g, m->lnpre_b, w.x, batch * T, W, w.x_dtype, s));
     const bf16_t* pending = nullptr;
     KEMR_TRY(run_blocks(m->vis, w, batch, 0, s, &pending));
-    KEMR_TRY(launch_tail(w.x, pending, nullptr, batch, T, W, m->lnpost_g, m->lnpost_b, m->vproj, m->cfg.embed_dim, normalize, out_dev, s));
+    KEMR_TRY(launch_tail(w.x, w.x_dtype, pending, nullptr, batch, T, W, m->lnpost_g, m->lnpost_b, m->vproj, m->cfg.embed_dim, normalize, out_dev, s));
     return KEMR_OK;
 }
 
@@ -374,11 +382,11 @@ extern "C" int kemr_encode_text(kemr_model* m, const int32_t* ids_dev, int batch
     hipStream_t s = (hipStream_t)stream;
     const int W = m->cfg.t_width, T = m->cfg.ctx;
     Workspace w;
-    KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, T, batch));
-    KEMR_TRY(launch_text_embed(ids_dev, m->tok, m->tpos, w.x, batch, T, W, m->cfg.vocab, s));
+    KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, T, batch, m->res_dtype));
+    KEMR_TRY(launch_text_embed(ids_dev, m->tok, m->tpos, w.x, w.x_dtype, batch, T, W, m->cfg.vocab, s));
     const bf16_t* pending = nullptr;
     KEMR_TRY(run_blocks(m->txt, w, batch, 1, s, &pending));
-    KEMR_TRY(launch_tail(w.x, pending, ids_dev, batch, T, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s));
+    KEMR_TRY(launch_tail(w.x, w.x_dtype, pending, ids_dev, batch, T, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s));
     return KEMR_OK;
 }
 
@@ -435,13 +443,19 @@ extern "C" int kemr_op_gemm(const void* a_dev, const void* w_dev, const float* b
 extern "C" int kemr_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, void* y_dev, int rows,
                                  int width, int out_dtype, void* stream) {
     if (!x_dev || !gamma_dev || !beta_dev || !y_dev) KEMR_FAIL(KEMR_ERR_INVALID, "op_layernorm: null argument");
-    return launch_layernorm((float*)x_dev, nullptr, gamma_dev, beta_dev, y_dev, rows, width, out_dtype, (hipStream_t)stream);
+    return launch_layernorm((void*)x_dev, KEMR_F32, nullptr, gamma_dev, beta_dev, y_dev, rows, width, out_dtype, (hipStream_t)stream);
 }
 
 extern "C" int kemr_op_layernorm_resid(float* x_dev, const void* delta_dev, const float* gamma_dev, const float* beta_dev,
                                        void* y_dev, int rows, int width, void* stream) {
     if (!x_dev || !delta_dev || !gamma_dev || !beta_dev || !y_dev) KEMR_FAIL(KEMR_ERR_INVALID, "op_layernorm_resid: null argument");
-    return launch_layernorm(x_dev, (const bf16_t*)delta_dev, gamma_dev, beta_dev, y_dev, rows, width, KEMR_BF16, (hipStream_t)stream);
+    return launch_layernorm(x_dev, KEMR_F32, (const bf16_t*)delta_dev, gamma_dev, beta_dev, y_dev, rows, width, KEMR_BF16, (hipStream_t)stream);
+}
+
+extern "C" int kemr_op_layernorm_rows(void* x_dev, int x_dtype, const void* delta_dev, const float* gamma_dev,
+                                      const float* beta_dev, void* y_dev, int rows, int width, int out_dtype, void* stream) {
+    if (!x_dev || !gamma_dev || !beta_dev || !y_dev) KEMR_FAIL(KEMR_ERR_INVALID, "op_layernorm_rows: null argument");
+    return launch_layernorm(x_dev, x_dtype, (const bf16_t*)delta_dev, gamma_dev, beta_dev, y_dev, rows, width, out_dtype, (hipStream_t)stream);
 }
 
 extern "C" int kemr_op_attention(const void* qkv_dev, void* out_dev, int batch, int t, int width, int causal, void* stream) {

@@ -65,8 +65,9 @@ int launch_cls_rows(float* x, const float* class_emb, const float* pos, int batc
     return KEMR_OK;
 }
 
+template <typename XT>
 __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids, const float* __restrict__ tok,
-                                                         const float* __restrict__ pos, float* __restrict__ x,
+                                                         const float* __restrict__ pos, XT* __restrict__ x,
                                                          int ctx, int width, int vocab, long long total4) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= total4) return;
@@ -78,16 +79,26 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // out-of-range ids are clamped (torch would raise)
     const float4 a = ((const float4*)(tok + (size_t)id * width))[c4];
     const float4 p = ((const float4*)(pos + (size_t)t * width))[c4];
-    ((float4*)(x + (size_t)row * width))[c4] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    if constexpr (sizeof(XT) == 4) {
+        ((float4*)(x + (size_t)row * width))[c4] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    } else {
+        uint2 pk;
+        pk.x = pack_bf16x2(a.x + p.x, a.y + p.y);
+        pk.y = pack_bf16x2(a.z + p.z, a.w + p.w);
+        ((uint2*)(x + (size_t)row * width))[c4] = pk;
+    }
 }
 
-int launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos, float* x, int batch, int ctx,
+int launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos, void* x, int x_dtype, int batch, int ctx,
                       int width, int vocab, hipStream_t stream) {
     const long long total4 = (long long)batch * ctx * (width / 4);
     if (total4 <= 0) return KEMR_OK;
     ProfScope prof(PROF_OTHER, stream);
-    hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, ids, tok_emb, pos,
-                       x, ctx, width, vocab, total4);
+    const dim3 grid((unsigned)((total4 + 255) / 256));
+    if (x_dtype == KEMR_BF16)
+        hipLaunchKernelGGL(text_embed_kernel<bf16_t>, grid, dim3(256), 0, stream, ids, tok_emb, pos, (bf16_t*)x, ctx, width, vocab, total4);
+    else
+        hipLaunchKernelGGL(text_embed_kernel<float>, grid, dim3(256), 0, stream, ids, tok_emb, pos, (float*)x, ctx, width, vocab, total4);
     KEMR_CHECK_LAUNCH("text_embed_kernel");
     return KEMR_OK;
 }
@@ -105,7 +116,8 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // grid (ceil(d / 64), batch): every workgroup re-normalises its row (width <= 1280 floats, trivial) so that no
 // intermediate buffer is needed; wave w owns 16 columns, lane (g = lane >> 2, jq = lane & 3) accumulates columns
 // 4*jq..4*jq+3 over the rows i = g (mod 16) with 16-byte loads of the fp32 projection, then 4 shuffle steps.
-__global__ __launch_bounds__(256) void tail_proj_kernel(const float* __restrict__ x, const bf16_t* __restrict__ delta,
+template <typename XT>
+__global__ __launch_bounds__(256) void tail_proj_kernel(const XT* __restrict__ x, const bf16_t* __restrict__ delta,
                                                         const int32_t* __restrict__ ids,
                                                         int tokens, int width, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ proj,
@@ -135,12 +147,14 @@ __global__ __launch_bounds__(256) void tail_proj_kernel(const float* __restrict_
     }
     __syncthreads();
     const size_t prow = (size_t)b * tokens + *pool;
-    const float* xr = x + prow * width;
+    const XT* xr = x + prow * width;
     const bf16_t* dr = delta ? delta + prow * width : nullptr;
 
     float s = 0.f;
     for (int i = tid; i < width; i += 256) {           // pooled row (+ the pending residual update) into LDS
-        const float v = xr[i] + (dr ? bf16_to_f32(dr[i]) : 0.f);
+        float v;
+        if constexpr (sizeof(XT) == 4) v = xr[i]; else v = bf16_to_f32(xr[i]);
+        if (dr) v += bf16_to_f32(dr[i]);
         y[i] = v;
         s += v;
     }
@@ -182,15 +196,18 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x,
     for (int i = lane; i < d; i += 64) r[i] *= inv;
 }
 
-int launch_tail(const float* x, const bf16_t* delta, const int32_t* ids, int batch, int tokens, int width, const float* gamma,
+int launch_tail(const void* x, int x_dtype, const bf16_t* delta, const int32_t* ids, int batch, int tokens, int width, const float* gamma,
                 const float* beta, const float* proj, int d, int normalize, float* out, hipStream_t stream) {
     if (batch <= 0) return KEMR_OK;
     if (d % 4 != 0 || d <= 0) KEMR_FAIL(KEMR_ERR_INVALID, "tail: embed_dim %d must be a positive multiple of 4", d);
     if (batch > 65535) KEMR_FAIL(KEMR_ERR_INVALID, "tail: batch %d > 65535", batch);
     const size_t smem = (size_t)width * 4 + 32;
     ProfScope prof(PROF_OTHER, stream);
-    hipLaunchKernelGGL(tail_proj_kernel, dim3((d + 63) / 64, batch), dim3(256), smem, stream, x, delta, ids, tokens, width, gamma,
-                       beta, proj, d, out);
+    const dim3 grid((d + 63) / 64, batch);
+    if (x_dtype == KEMR_BF16)
+        hipLaunchKernelGGL(tail_proj_kernel<bf16_t>, grid, dim3(256), smem, stream, (const bf16_t*)x, delta, ids, tokens, width, gamma, beta, proj, d, out);
+    else
+        hipLaunchKernelGGL(tail_proj_kernel<float>, grid, dim3(256), smem, stream, (const float*)x, delta, ids, tokens, width, gamma, beta, proj, d, out);
     KEMR_CHECK_LAUNCH("tail_proj_kernel");
     if (normalize) {
         hipLaunchKernelGGL(l2norm_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, stream, out, batch, d);

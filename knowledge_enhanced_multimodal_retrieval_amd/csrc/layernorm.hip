@@ -1,7 +1,7 @@
-// LayerNorm over the residual stream: fp32 rows in, bf16 (GEMM operand) or fp32 (ln_pre, in place) out.
-// HBM-bound: one wave per row, the whole row lives in registers (float4 loads, 16 B / lane), mean and
-// variance by wave shuffles (two-pass, like torch's fp32 LayerNorm), 8-byte bf16 stores.
-// Algorithmic bytes per row: width * (4 read + 2 written) [+ 8 * width once for gamma/beta, L2-resident].
+// LayerNorm over the residual stream: fp32 (or, KEMR_PREC_BF16_RES16, bf16) rows in, bf16 (GEMM operand) or fp32
+// (ln_pre, in place) out.  HBM-bound: one wave per row, the whole row lives in registers (16 B / lane loads for fp32
+// rows, 8 B for bf16), mean and variance by wave shuffles in fp32 (two-pass, like torch's fp32 LayerNorm), 8-byte
+// bf16 stores.  Algorithmic bytes per row: width * (4|2 read + 2 written) [+ 8 * width once for gamma/beta, L2-resident].
 #include "common.h"
 
 namespace kemr {
@@ -9,25 +9,38 @@ namespace kemr {
 // RESID: the residual update of the preceding GEMM is fused here.  That GEMM stored its output (bias included) as a
 // bf16 "delta" (store-only epilogue, overlapped by the persistent GEMM kernel); this kernel computes x += delta, writes
 // the fp32 residual stream back and normalises the updated row: 4 + 2 bytes read, 4 + 2 written per element.
-template <int NV, typename OutT, bool RESID>   // width = NV * 256
-__global__ __launch_bounds__(256) void layernorm_kernel(float* x, const bf16_t* __restrict__ delta,
+__device__ __forceinline__ float4 load_row4(const float* r, int i) { return ((const float4*)r)[i]; }
+__device__ __forceinline__ float4 load_row4(const bf16_t* r, int i) {
+    const uint2 d = ((const uint2*)r)[i];
+    return make_float4(bf16_to_f32((bf16_t)(d.x & 0xffff)), bf16_to_f32((bf16_t)(d.x >> 16)),
+                       bf16_to_f32((bf16_t)(d.y & 0xffff)), bf16_to_f32((bf16_t)(d.y >> 16)));
+}
+__device__ __forceinline__ void store_row4(float* r, int i, float4 v) { ((float4*)r)[i] = v; }
+__device__ __forceinline__ void store_row4(bf16_t* r, int i, float4 v) {
+    uint2 pk;
+    pk.x = pack_bf16x2(v.x, v.y);
+    pk.y = pack_bf16x2(v.z, v.w);
+    ((uint2*)r)[i] = pk;
+}
+
+template <int NV, typename XT, typename OutT, bool RESID>   // width = NV * 256
+__global__ __launch_bounds__(256) void layernorm_kernel(XT* x, const bf16_t* __restrict__ delta,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         OutT* y, int rows, float eps) {
     constexpr int W = NV * 256;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    float4* xr = (float4*)(x + (size_t)row * W);
+    XT* xr = x + (size_t)row * W;
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        v[i] = xr[i * 64 + lane];
+        v[i] = load_row4(xr, i * 64 + lane);
         if constexpr (RESID) {
-            const uint2 d = ((const uint2*)(delta + (size_t)row * W))[i * 64 + lane];
-            v[i].x += bf16_to_f32((bf16_t)(d.x & 0xffff)); v[i].y += bf16_to_f32((bf16_t)(d.x >> 16));
-            v[i].z += bf16_to_f32((bf16_t)(d.y & 0xffff)); v[i].w += bf16_to_f32((bf16_t)(d.y >> 16));
-            xr[i * 64 + lane] = v[i];
+            const float4 d = load_row4(delta + (size_t)row * W, i * 64 + lane);
+            v[i].x += d.x; v[i].y += d.y; v[i].z += d.z; v[i].w += d.w;
+            store_row4(xr, i * 64 + lane, v[i]);     // a bf16 stream rounds here; the statistics use the fp32 sum
         }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
@@ -48,38 +61,28 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* x, const bf16_t* 
         o.y = v[i].y * rstd * g.y + b.y;
         o.z = v[i].z * rstd * g.z + b.z;
         o.w = v[i].w * rstd * g.w + b.w;
-        if constexpr (sizeof(OutT) == 2) {
-            uint2 pk;
-            pk.x = pack_bf16x2(o.x, o.y);
-            pk.y = pack_bf16x2(o.z, o.w);
-            ((uint2*)((bf16_t*)y + (size_t)row * W))[i * 64 + lane] = pk;
-        } else {
-            ((float4*)((float*)y + (size_t)row * W))[i * 64 + lane] = o;
-        }
+        store_row4(y + (size_t)row * W, i * 64 + lane, o);
     }
 }
 
-template <int NV>
-static int launch_nv(float* x, const bf16_t* delta, const float* g, const float* b, void* y, int rows, int out_dtype,
+template <int NV, typename XT>
+static int launch_nv(XT* x, const bf16_t* delta, const float* g, const float* b, void* y, int rows, int out_dtype,
                      hipStream_t s) {
     const int blocks = (rows + 3) / 4;
     ProfScope prof(PROF_LAYERNORM, s);
     if (delta)
-        hipLaunchKernelGGL((layernorm_kernel<NV, bf16_t, true>), dim3(blocks), dim3(256), 0, s, x, delta, g, b, (bf16_t*)y, rows, 1e-5f);
+        hipLaunchKernelGGL((layernorm_kernel<NV, XT, bf16_t, true>), dim3(blocks), dim3(256), 0, s, x, delta, g, b, (bf16_t*)y, rows, 1e-5f);
     else if (out_dtype == KEMR_BF16)
-        hipLaunchKernelGGL((layernorm_kernel<NV, bf16_t, false>), dim3(blocks), dim3(256), 0, s, x, delta, g, b, (bf16_t*)y, rows, 1e-5f);
+        hipLaunchKernelGGL((layernorm_kernel<NV, XT, bf16_t, false>), dim3(blocks), dim3(256), 0, s, x, delta, g, b, (bf16_t*)y, rows, 1e-5f);
     else
-        hipLaunchKernelGGL((layernorm_kernel<NV, float, false>), dim3(blocks), dim3(256), 0, s, x, delta, g, b, (float*)y, rows, 1e-5f);
+        hipLaunchKernelGGL((layernorm_kernel<NV, XT, float, false>), dim3(blocks), dim3(256), 0, s, x, delta, g, b, (float*)y, rows, 1e-5f);
     KEMR_CHECK_LAUNCH("layernorm_kernel");
     return KEMR_OK;
 }
 
-// delta != nullptr: x += delta first (x is updated in place; the output is bf16)
-int launch_layernorm(float* x, const bf16_t* delta, const float* gamma, const float* beta, void* y, int rows, int width,
+template <typename XT>
+static int launch_xt(XT* x, const bf16_t* delta, const float* gamma, const float* beta, void* y, int rows, int width,
                      int out_dtype, hipStream_t stream) {
-    if (rows <= 0) return KEMR_OK;
-    if (out_dtype != KEMR_BF16 && out_dtype != KEMR_F32) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: bad out dtype %d", out_dtype);
-    if (delta && out_dtype != KEMR_BF16) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: the residual form writes bf16");
     switch (width) {
         case 256:  return launch_nv<1>(x, delta, gamma, beta, y, rows, out_dtype, stream);
         case 512:  return launch_nv<2>(x, delta, gamma, beta, y, rows, out_dtype, stream);
@@ -88,6 +91,17 @@ int launch_layernorm(float* x, const bf16_t* delta, const float* gamma, const fl
         case 1280: return launch_nv<5>(x, delta, gamma, beta, y, rows, out_dtype, stream);
     }
     KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: width %d not in {256,512,768,1024,1280}", width);
+}
+
+// x_dtype: KEMR_F32 or KEMR_BF16 rows.  delta != nullptr: x += delta first (x is updated in place; the output is bf16)
+int launch_layernorm(void* x, int x_dtype, const bf16_t* delta, const float* gamma, const float* beta, void* y, int rows,
+                     int width, int out_dtype, hipStream_t stream) {
+    if (rows <= 0) return KEMR_OK;
+    if (out_dtype != KEMR_BF16 && out_dtype != KEMR_F32) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: bad out dtype %d", out_dtype);
+    if (x_dtype != KEMR_BF16 && x_dtype != KEMR_F32) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: bad row dtype %d", x_dtype);
+    if (delta && out_dtype != KEMR_BF16) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: the residual form writes bf16");
+    if (x_dtype == KEMR_BF16) return launch_xt((bf16_t*)x, delta, gamma, beta, y, rows, width, out_dtype, stream);
+    return launch_xt((float*)x, delta, gamma, beta, y, rows, width, out_dtype, stream);
 }
 
 }  // namespace kemr

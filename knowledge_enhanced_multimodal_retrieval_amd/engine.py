@@ -31,7 +31,11 @@ def _require_cuda(t: torch.Tensor, what: str) -> None:
 class ClipEngine:
     """One packed CLIP model (both towers) in HBM."""
 
-    def __init__(self, arch: ClipArch, device: torch.device | str = "cuda:0"):
+    def __init__(self, arch: ClipArch, device: torch.device | str = "cuda:0", precision: str = "bf16"):
+        """precision: "bf16" (fp32 residual stream) or "bf16-res16" (bf16 residual stream, see include/kemr.h)."""
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
+        self.precision = precision
         self.arch = arch
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -67,7 +71,7 @@ class ClipEngine:
             _lib.check(self._L.kemr_model_load_tensor(self._h, name.encode(), C.c_void_p(host.data_ptr()), _lib.KEMR_F32,
                                                       shape, host.dim()), f"load_tensor({name})")
         with torch.cuda.device(self.device):
-            _lib.check(self._L.kemr_model_finalize(self._h, _lib.PREC_BF16), "model_finalize")
+            _lib.check(self._L.kemr_model_finalize(self._h, _lib.PRECISIONS[self.precision]), "model_finalize")
         self.ready = True
 
     # ------------------------------------------------------------------ encoders
@@ -329,6 +333,23 @@ def op_layernorm_resid(x: torch.Tensor, delta: torch.Tensor, gamma: torch.Tensor
         _lib.check(L.kemr_op_layernorm_resid(C.c_void_p(x.data_ptr()), C.c_void_p(delta.data_ptr()), C.c_void_p(gamma.data_ptr()),
                                              C.c_void_p(beta.data_ptr()), C.c_void_p(y.data_ptr()), rows, width,
                                              C.c_void_p(_stream_ptr(x.device))), "op_layernorm_resid")
+    return y
+
+
+def op_layernorm_rows(x: torch.Tensor, delta: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+                      out_bf16: bool = True) -> torch.Tensor:
+    """General form: x is fp32 or bf16 rows; with `delta` (bf16) x += delta is written back in x's dtype first."""
+    L = _lib.lib()
+    rows, width = x.shape
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("op_layernorm_rows: x must be fp32 or bf16")
+    y = torch.empty((rows, width), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(L.kemr_op_layernorm_rows(C.c_void_p(x.data_ptr()), _lib.KEMR_BF16 if x.dtype == torch.bfloat16 else _lib.KEMR_F32,
+                                            _opt_ptr(delta), C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()),
+                                            C.c_void_p(y.data_ptr()), rows, width,
+                                            _lib.KEMR_BF16 if out_bf16 else _lib.KEMR_F32,
+                                            C.c_void_p(_stream_ptr(x.device))), "op_layernorm_rows")
     return y
 
 

@@ -18,17 +18,21 @@ def _cos(a, b):
     return torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=-1)
 
 
-def _engine(name, device, seed=0):
+PRECISIONS = ["bf16", "bf16-res16"]     # fp32 / bf16 residual stream (include/kemr.h kemr_precision)
+
+
+def _engine(name, device, seed=0, precision="bf16"):
     arch = ARCHS[name]
     sd = clip_ref.random_state_dict(clip_ref.ARCHS[name], seed=seed)
-    eng = engine.ClipEngine(arch, device)
+    eng = engine.ClipEngine(arch, device, precision=precision)
     eng.load_state_dict(sd)
     return arch, sd, eng
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name,nimg,ntxt", [("tiny", 9, 11), ("tiny-long", 5, 7)])
-def test_tiny_archs_match_oracle(device, name, nimg, ntxt):
-    arch, sd, eng = _engine(name, device)
+def test_tiny_archs_match_oracle(device, name, nimg, ntxt, precision):
+    arch, sd, eng = _engine(name, device, precision=precision)
     oa = clip_ref.ARCHS[name]
     g = torch.Generator().manual_seed(1234)
     px = torch.randn(nimg, 3, arch.image_size, arch.image_size, generator=g)
@@ -37,7 +41,7 @@ def test_tiny_archs_match_oracle(device, name, nimg, ntxt):
     got_i = eng.encode_image(px.to(device)).cpu()
     got_t = eng.encode_text(ids.to(device)).cpu()
     ci, ct = _cos(got_i, ref_i), _cos(got_t, ref_t)
-    print(f"{name}: image cos min {ci.min():.6f}, text cos min {ct.min():.6f}")
+    print(f"{name} {precision}: image cos min {ci.min():.6f}, text cos min {ct.min():.6f}")
     assert float((1 - ci).max()) < COS_TOL and float((1 - ct).max()) < COS_TOL
     # un-normalised outputs keep their scale; normalised ones are unit length and equal the oracle's rule
     assert float((got_i.norm(dim=-1) / ref_i.norm(dim=-1) - 1).abs().max()) < 2e-2
@@ -46,10 +50,11 @@ def test_tiny_archs_match_oracle(device, name, nimg, ntxt):
     assert float((got_n - got_i / got_i.norm(dim=-1, keepdim=True)).abs().max()) < 1e-5
 
 
-def test_golden_hf_fixture(device, golden_dir):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_golden_hf_fixture(device, golden_dir, precision):
     """Same inputs as the committed HF-from-config vectors (tests/golden/clip_hf_tiny-long.npz)."""
     z = np.load(os.path.join(golden_dir, "clip_hf_tiny-long.npz"))
-    arch, sd, eng = _engine("tiny-long", device)
+    arch, sd, eng = _engine("tiny-long", device, precision=precision)
     got_i = eng.encode_image(torch.from_numpy(z["pixels"]).to(device)).cpu()
     got_t = eng.encode_text(torch.from_numpy(z["ids"]).to(device)).cpu()
     assert float((1 - _cos(got_i, torch.from_numpy(z["image_features"]))).max()) < COS_TOL
@@ -103,10 +108,11 @@ def test_strict_load_errors(device):
         eng.encode_image(torch.zeros(1, 3, 32, 32))
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name,nimg,ntxt", [("ViT-B/32", 3, 4), ("ViT-L/14", 2, 3)])
-def test_full_size_models_match_oracle(device, name, nimg, ntxt):
+def test_full_size_models_match_oracle(device, name, nimg, ntxt, precision):
     """BASELINE configs[0]/[1] architectures at full width/depth on a few items (the CPU oracle takes seconds)."""
-    arch, sd, eng = _engine(name, device)
+    arch, sd, eng = _engine(name, device, precision=precision)
     oa = clip_ref.ARCHS[name]
     g = torch.Generator().manual_seed(1234)
     px = torch.randn(nimg, 3, 224, 224, generator=g)
@@ -115,5 +121,5 @@ def test_full_size_models_match_oracle(device, name, nimg, ntxt):
     got_i = eng.encode_image(px.to(device)).cpu()
     got_t = eng.encode_text(ids.to(device)).cpu()
     ci, ct = _cos(got_i, ref_i), _cos(got_t, ref_t)
-    print(f"{name}: image cos min {ci.min():.6f}, text cos min {ct.min():.6f}")
+    print(f"{name} {precision}: image 1-cos max {float((1 - ci).max()):.2e}, text 1-cos max {float((1 - ct).max()):.2e}")
     assert float((1 - ci).max()) < COS_TOL and float((1 - ct).max()) < COS_TOL

@@ -158,6 +158,33 @@ def test_layernorm_with_fused_residual(device, width):
     assert float((y.float().cpu() - ref).abs().max()) < 2e-2
 
 
+@pytest.mark.parametrize("width", [256, 768, 1024])
+def test_layernorm_bf16_rows(device, width):
+    """KEMR_PREC_BF16_RES16: the residual stream is stored as bf16; the add and the statistics stay fp32."""
+    g = torch.Generator().manual_seed(width + 2)
+    rows = 301
+    x = (torch.randn(rows, width, generator=g) * 2).to(torch.bfloat16)
+    delta = (torch.randn(rows, width, generator=g) * 0.5).to(torch.bfloat16)
+    gamma, beta = 1 + 0.1 * torch.randn(width, generator=g), 0.1 * torch.randn(width, generator=g)
+    gd, bd = gamma.to(device), beta.to(device)
+    xs = x.float() + delta.float()
+    xd = x.clone().to(device)
+    y = engine.op_layernorm_rows(xd, delta.to(device), gd, bd)
+    torch.cuda.synchronize()
+    assert torch.equal(xd.cpu(), xs.to(torch.bfloat16))              # written back with one RNE rounding
+    assert float((y.float().cpu() - torch.nn.functional.layer_norm(xs, (width,), gamma, beta, 1e-5)).abs().max()) < 2e-2
+    # without a delta x is only read; fp32 output of bf16 rows; bf16 rows normalised in place (ln_pre form)
+    y32 = engine.op_layernorm_rows(xd, None, gd, bd, out_bf16=False)
+    ref = torch.nn.functional.layer_norm(xd.float().cpu(), (width,), gamma, beta, 1e-5)
+    assert float((y32.cpu() - ref).abs().max()) < 2e-5
+    L = _lib.lib()
+    import ctypes as C
+    _lib.check(L.kemr_op_layernorm_rows(C.c_void_p(xd.data_ptr()), _lib.KEMR_BF16, None, C.c_void_p(gd.data_ptr()),
+                                        C.c_void_p(bd.data_ptr()), C.c_void_p(xd.data_ptr()), rows, width, _lib.KEMR_BF16, None))
+    torch.cuda.synchronize()
+    assert float((xd.float().cpu() - ref).abs().max()) < 4e-2
+
+
 def _attention_ref(qkv, batch, t, width, causal):
     heads = width // 64
     q, k, v = qkv.float().view(batch, t, 3, heads, 64).permute(2, 0, 3, 1, 4)      # [B,H,T,64]; q already scaled
