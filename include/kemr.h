@@ -203,9 +203,10 @@ typedef enum kemr_epilogue {
 } kemr_epilogue;
 /* A bf16 [m_alloc, k] and C [m_alloc, n] with m_alloc = m rounded up to 256 rows (pad rows of A are read; pad rows of C
  * may be written by the bf16 epilogues), W bf16 [n, k], bias fp32 [n] */
-/* tile variant used by every GEMM launch: 0 = automatic (default), 1 = 128x128x64 / 4 waves, 2 = 256x256x64 / 8 waves in
- * lockstep, 3 = 256x256x64 / 8 waves with staggered halves, 4 = persistent 256x256 with asynchronous epilogue (bf16
- * epilogues; 2-4 wherever N % 256 == 0); A/B benchmarking and tests */
+/* tile variant used by every GEMM launch: 0 = automatic (default: 7 for the bf16 epilogues from 128 tiles up), 1 = 128x128x64
+ * / 4 waves, 2 = 256x256x64 / 8 waves in lockstep, 3 = the same with staggered wave halves, 4 / 5 = persistent 256x256 with a
+ * per-tile prologue (4 / 2 phases per K-tile), 6 = persistent, 4 waves x 128x128 (AGPR accumulators), 7 = persistent 8 waves,
+ * one K-tile pipeline across tiles, non-temporal C stores (2-7 need N % 256 == 0; 4-7 the bf16 epilogues); A/B and tests */
 int kemr_set_gemm_variant(int variant);
 int kemr_op_gemm(const void* a_dev, const void* w_dev, const float* bias_dev, void* c_dev,
                  int m, int n, int k, int epilogue, void* stream);

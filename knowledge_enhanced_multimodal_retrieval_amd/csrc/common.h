@@ -84,7 +84,7 @@ struct GemmParams {
     int M, N, K;         // M = valid rows (stores are guarded), N % 128 == 0, K % 64 == 0
     int lda, ldw, ldc;
     int patches;         // EPI_PATCH_F32: patches per image (row remap m -> m + m / patches + 1)
-    int dbg;             // timing experiments only (tools/): bit 0 = skip the epilogue stores
+    int dbg;             // timing experiments only (tools/): bit 0 = skip the epilogue stores; gemm256u: 4 = plain (not nt) stores, 32 = half the stores
     int c_rows_padded;   // C has ceil256(M) writable rows (lets the persistent kernel store without row masks)
 };
 extern int g_gemm_dbg;
@@ -92,6 +92,8 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);      // picks
 int launch_gemm256(const GemmParams& p, int epi, hipStream_t stream);   // gemm256.hip: 256x256x64, 8 waves, counted vmcnt
 int launch_gemm256p(const GemmParams& p, int epi, hipStream_t stream);  // gemm256p.hip: persistent, async epilogue (bf16-store epilogues)
 int launch_gemm256q(const GemmParams& p, int epi, hipStream_t stream);  // gemm256q.hip: persistent, 2 long phases per K-tile
+int launch_gemm256u(const GemmParams& p, int epi, hipStream_t stream);  // gemm256u.hip: gemm256p's K loop, one K-tile pipeline across tiles
+int launch_gemm256w(const GemmParams& p, int epi, hipStream_t stream);  // gemm256w.hip: persistent, 4 waves x 128x128 (AGPR accumulators)
 extern int g_gemm_variant;   // 0 auto, 1 = 128x128 (gemm.hip), 2 / 3 = 256x256 lockstep / staggered, 4 = persistent 256x256 (bf16 epilogues)
 
 // ---- other launchers --------------------------------------------------------------------------

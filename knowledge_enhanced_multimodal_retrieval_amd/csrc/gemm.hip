@@ -180,8 +180,10 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     const long tiles256 = (long)((p.M + 255) / 256) * (p.N / 256);
     const bool bf16_epi = epi == EPI_BIAS_BF16 || epi == EPI_BIAS_QGELU_BF16;
     if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 5) return launch_gemm256q(p, epi, stream);
-    if (can256 && bf16_epi && p.c_rows_padded && (g_gemm_variant == 4 || (g_gemm_variant == 0 && tiles256 >= 128)))
-        return launch_gemm256p(p, epi, stream);
+    if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 6) return launch_gemm256w(p, epi, stream);
+    if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 4) return launch_gemm256p(p, epi, stream);
+    if (can256 && bf16_epi && p.c_rows_padded && (g_gemm_variant == 7 || (g_gemm_variant == 0 && tiles256 >= 128)))
+        return launch_gemm256u(p, epi, stream);
     if (can256 && (g_gemm_variant >= 2 || (g_gemm_variant == 0 && tiles256 >= 128))) return launch_gemm256(p, epi, stream);
     switch (epi) {
         case EPI_BIAS_BF16:       return launch_cfg<128, 128, 2, 2, EPI_BIAS_BF16>(p, stream);
