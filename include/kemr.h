@@ -215,9 +215,11 @@ int kemr_op_layernorm(const float* x_dev, const float* gamma_dev, const float* b
 /* fused residual form used inside the towers: x_f32 += delta_bf16 (written back), y_bf16 = LayerNorm(x) */
 int kemr_op_layernorm_resid(float* x_dev, const void* delta_dev, const float* gamma_dev, const float* beta_dev,
                             void* y_dev, int rows, int width, void* stream);
-/* general form: rows of x_dtype (KEMR_F32|KEMR_BF16); delta_dev may be NULL (then x is only read, unless y_dev == x_dev) */
-int kemr_op_layernorm_rows(void* x_dev, int x_dtype, const void* delta_dev, const float* gamma_dev, const float* beta_dev,
-                           void* y_dev, int rows, int width, int out_dtype, void* stream);
+/* general form: rows of x_dtype (KEMR_F32|KEMR_BF16); y = LayerNorm(x [+ delta [+ delta2]]) (deltas bf16, may be NULL);
+ * writeback != 0 stores the sum back into x (required with delta2); without deltas x is only read, unless y_dev == x_dev */
+int kemr_op_layernorm_rows(void* x_dev, int x_dtype, const void* delta_dev, const void* delta2_dev, int writeback,
+                           const float* gamma_dev, const float* beta_dev, void* y_dev, int rows, int width, int out_dtype,
+                           void* stream);
 /* qkv bf16 [batch*t, 3*width] (q pre-scaled by 1/8) -> out bf16 [batch*t, width] */
 int kemr_op_attention(const void* qkv_dev, void* out_dev, int batch, int t, int width, int causal, void* stream);
 

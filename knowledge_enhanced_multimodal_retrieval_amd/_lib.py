@@ -60,7 +60,7 @@ SIGNATURES = {
     "kemr_op_gemm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "kemr_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "kemr_op_layernorm_resid": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
-    "kemr_op_layernorm_rows": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "kemr_op_layernorm_rows": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "kemr_op_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
 }
 

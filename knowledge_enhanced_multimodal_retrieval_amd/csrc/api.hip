@@ -287,7 +287,8 @@ struct Workspace {
     int x_dtype;
     bf16_t* h;      // [Mp, W] bf16: LayerNorm output / attention output (GEMM A operand)
     bf16_t* big;    // [Mp, 4W] bf16: qkv (ld 3W), MLP hidden (ld 4W), im2col patches
-    bf16_t* delta;  // [Mp, W] bf16: output of the out-proj / fc2 GEMMs, added to x by the next LayerNorm (or the tail)
+    bf16_t* delta;  // [Mp, W] bf16: output of the out-proj GEMM (attention update), pending until the next block's ln_1
+    bf16_t* delta2; // [Mp, W] bf16: output of the fc2 GEMM (MLP update), pending until the next block's ln_1 (or the tail)
     float* x32;     // [Mp, W] fp32 front-end rows of the vision tower (patch GEMM + cls, read by ln_pre): x itself for
                     // an fp32 stream, else the (then still unused) h | delta pair, which is contiguous and as large
 };
@@ -295,7 +296,7 @@ struct Workspace {
 size_t ws_bytes(int width, int tokens, int batch, int x_dtype) {
     const int64_t Mp = round_up((int64_t)batch * tokens, 256);
     const int xb = x_dtype == KEMR_BF16 ? 2 : 4;
-    return (size_t)(round_up(Mp * width * xb, 256) + 2 * round_up(Mp * width * 2, 256) + round_up(Mp * width * 8, 256));
+    return (size_t)(round_up(Mp * width * xb, 256) + 3 * round_up(Mp * width * 2, 256) + round_up(Mp * width * 8, 256));
 }
 
 int carve(Workspace& w, void* base, size_t bytes, int width, int tokens, int batch, int x_dtype) {
@@ -308,20 +309,20 @@ int carve(Workspace& w, void* base, size_t bytes, int width, int tokens, int bat
     w.x32 = x_dtype == KEMR_BF16 ? (float*)p : (float*)w.x;
     w.h = (bf16_t*)p; p += round_up(Mp * width * 2, 256);
     w.delta = (bf16_t*)p; p += round_up(Mp * width * 2, 256);
+    w.delta2 = (bf16_t*)p; p += round_up(Mp * width * 2, 256);
     w.big = (bf16_t*)p;
     return KEMR_OK;
 }
 
-// Residual blocks.  The out-proj and fc2 GEMMs do not read-modify-write the fp32 residual stream: they store
-// `A.W^T + bias` as bf16 into `delta` (store-only epilogue, overlapped with the next tile by the persistent GEMM) and the
-// following LayerNorm applies x += delta while it reads x anyway.  On return `*pending` is the last block's delta that
-// the caller's tail still has to add.
-int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, hipStream_t s, const bf16_t** pending) {
+// Residual blocks.  The out-proj and fc2 GEMMs do not read-modify-write the residual stream: they store `A.W^T + bias`
+// as bf16 into `delta` / `delta2` (store-only epilogues) and the LayerNorms apply the updates while they read x anyway:
+// ln_2 normalises x + delta without writing x; the next block's ln_1 writes x += delta + delta2 once and normalises it.
+// On return both deltas of the last block are still pending; the caller's tail adds them.
+int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, hipStream_t s) {
     const int W = t.width, M = batch * t.tokens;
-    const bf16_t* carry = nullptr;
     for (int l = 0; l < t.layers; ++l) {
         const LayerW& L = t.layer[l];
-        KEMR_TRY(launch_layernorm(w.x, w.x_dtype, carry, L.ln1_g, L.ln1_b, w.h, M, W, KEMR_BF16, s));
+        KEMR_TRY(launch_layernorm(w.x, w.x_dtype, l ? w.delta : nullptr, l ? w.delta2 : nullptr, 1, L.ln1_g, L.ln1_b, w.h, M, W, KEMR_BF16, s));
         GemmParams g{};
         g.M = M;
         g.c_rows_padded = 1;       // every workspace buffer has ceil256(M) rows
@@ -330,14 +331,12 @@ int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, hipSt
         KEMR_TRY(launch_attention(w.big, w.h, batch, t.tokens, W, causal, s));
         g.A = w.h; g.lda = W; g.W = L.wo; g.ldw = W; g.bias = L.bo; g.C = w.delta; g.ldc = W; g.N = W; g.K = W;
         KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
-        KEMR_TRY(launch_layernorm(w.x, w.x_dtype, w.delta, L.ln2_g, L.ln2_b, w.h, M, W, KEMR_BF16, s));
+        KEMR_TRY(launch_layernorm(w.x, w.x_dtype, w.delta, nullptr, 0, L.ln2_g, L.ln2_b, w.h, M, W, KEMR_BF16, s));
         g.A = w.h; g.lda = W; g.W = L.w1; g.ldw = W; g.bias = L.b1; g.C = w.big; g.ldc = 4 * W; g.N = 4 * W; g.K = W;
         KEMR_TRY(launch_gemm(g, EPI_BIAS_QGELU_BF16, s));
-        g.A = w.big; g.lda = 4 * W; g.W = L.w2; g.ldw = 4 * W; g.bias = L.b2; g.C = w.delta; g.ldc = W; g.N = W; g.K = 4 * W;
+        g.A = w.big; g.lda = 4 * W; g.W = L.w2; g.ldw = 4 * W; g.bias = L.b2; g.C = w.delta2; g.ldc = W; g.N = W; g.K = 4 * W;
         KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
-        carry = w.delta;
     }
-    *pending = carry;
     return KEMR_OK;
 }
 
@@ -366,10 +365,10 @@ extern "C" int kemr_encode_image(kemr_model* m, const float* pixels_dev, int bat
     g.pos = m->vpos; g.patches = m->patches; g.M = batch * m->patches; g.N = W; g.K = m->kpad;
     KEMR_TRY(launch_gemm(g, EPI_PATCH_F32, s));
     KEMR_TRY(launch_cls_rows(w.x32, m->cls, m->vpos, batch, T, W, s));
-    KEMR_TRY(launch_layernorm(w.x32, KEMR_F32, nullptr, m->lnpre_g, m->lnpre_b, w.x, batch * T, W, w.x_dtype, s));
-    const bf16_t* pending = nullptr;
-    KEMR_TRY(run_blocks(m->vis, w, batch, 0, s, &pending));
-    KEMR_TRY(launch_tail(w.x, w.x_dtype, pending, nullptr, batch, T, W, m->lnpost_g, m->lnpost_b, m->vproj, m->cfg.embed_dim, normalize, out_dev, s));
+    KEMR_TRY(launch_layernorm(w.x32, KEMR_F32, nullptr, nullptr, 0, m->lnpre_g, m->lnpre_b, w.x, batch * T, W, w.x_dtype, s));
+    KEMR_TRY(run_blocks(m->vis, w, batch, 0, s));
+    const bool vb = m->vis.layers > 0;
+    KEMR_TRY(launch_tail(w.x, w.x_dtype, vb ? w.delta : nullptr, vb ? w.delta2 : nullptr, nullptr, batch, T, W, m->lnpost_g, m->lnpost_b, m->vproj, m->cfg.embed_dim, normalize, out_dev, s));
     return KEMR_OK;
 }
 
@@ -384,9 +383,9 @@ extern "C" int kemr_encode_text(kemr_model* m, const int32_t* ids_dev, int batch
     Workspace w;
     KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, T, batch, m->res_dtype));
     KEMR_TRY(launch_text_embed(ids_dev, m->tok, m->tpos, w.x, w.x_dtype, batch, T, W, m->cfg.vocab, s));
-    const bf16_t* pending = nullptr;
-    KEMR_TRY(run_blocks(m->txt, w, batch, 1, s, &pending));
-    KEMR_TRY(launch_tail(w.x, w.x_dtype, pending, ids_dev, batch, T, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s));
+    KEMR_TRY(run_blocks(m->txt, w, batch, 1, s));
+    const bool tb = m->txt.layers > 0;
+    KEMR_TRY(launch_tail(w.x, w.x_dtype, tb ? w.delta : nullptr, tb ? w.delta2 : nullptr, ids_dev, batch, T, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s));
     return KEMR_OK;
 }
 
@@ -443,19 +442,21 @@ extern "C" int kemr_op_gemm(const void* a_dev, const void* w_dev, const float* b
 extern "C" int kemr_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, void* y_dev, int rows,
                                  int width, int out_dtype, void* stream) {
     if (!x_dev || !gamma_dev || !beta_dev || !y_dev) KEMR_FAIL(KEMR_ERR_INVALID, "op_layernorm: null argument");
-    return launch_layernorm((void*)x_dev, KEMR_F32, nullptr, gamma_dev, beta_dev, y_dev, rows, width, out_dtype, (hipStream_t)stream);
+    return launch_layernorm((void*)x_dev, KEMR_F32, nullptr, nullptr, 0, gamma_dev, beta_dev, y_dev, rows, width, out_dtype, (hipStream_t)stream);
 }
 
 extern "C" int kemr_op_layernorm_resid(float* x_dev, const void* delta_dev, const float* gamma_dev, const float* beta_dev,
                                        void* y_dev, int rows, int width, void* stream) {
     if (!x_dev || !delta_dev || !gamma_dev || !beta_dev || !y_dev) KEMR_FAIL(KEMR_ERR_INVALID, "op_layernorm_resid: null argument");
-    return launch_layernorm(x_dev, KEMR_F32, (const bf16_t*)delta_dev, gamma_dev, beta_dev, y_dev, rows, width, KEMR_BF16, (hipStream_t)stream);
+    return launch_layernorm(x_dev, KEMR_F32, (const bf16_t*)delta_dev, nullptr, 1, gamma_dev, beta_dev, y_dev, rows, width, KEMR_BF16, (hipStream_t)stream);
 }
 
-extern "C" int kemr_op_layernorm_rows(void* x_dev, int x_dtype, const void* delta_dev, const float* gamma_dev,
-                                      const float* beta_dev, void* y_dev, int rows, int width, int out_dtype, void* stream) {
+extern "C" int kemr_op_layernorm_rows(void* x_dev, int x_dtype, const void* delta_dev, const void* delta2_dev, int writeback,
+                                      const float* gamma_dev, const float* beta_dev, void* y_dev, int rows, int width,
+                                      int out_dtype, void* stream) {
     if (!x_dev || !gamma_dev || !beta_dev || !y_dev) KEMR_FAIL(KEMR_ERR_INVALID, "op_layernorm_rows: null argument");
-    return launch_layernorm(x_dev, x_dtype, (const bf16_t*)delta_dev, gamma_dev, beta_dev, y_dev, rows, width, out_dtype, (hipStream_t)stream);
+    return launch_layernorm(x_dev, x_dtype, (const bf16_t*)delta_dev, (const bf16_t*)delta2_dev, writeback, gamma_dev, beta_dev,
+                            y_dev, rows, width, out_dtype, (hipStream_t)stream);
 }
 
 extern "C" int kemr_op_attention(const void* qkv_dev, void* out_dev, int batch, int t, int width, int causal, void* stream) {

@@ -99,16 +99,17 @@ extern int g_gemm_variant;   // 0 auto, 1 = 128x128 (gemm.hip), 2 / 3 = 256x256 
 // ---- other launchers --------------------------------------------------------------------------
 // delta != nullptr: x += delta (bf16 [rows, width], the previous GEMM's output) is applied first and written back
 // x_dtype (KEMR_F32 / KEMR_BF16) is the storage type of the residual rows
-int launch_layernorm(void* x, int x_dtype, const bf16_t* delta, const float* gamma, const float* beta, void* y, int rows,
-                     int width, int out_dtype, hipStream_t stream);
+// delta2 (needs delta and writeback) is added as well; writeback == 0 leaves x as it is and normalises x + delta
+int launch_layernorm(void* x, int x_dtype, const bf16_t* delta, const bf16_t* delta2, int writeback, const float* gamma,
+                     const float* beta, void* y, int rows, int width, int out_dtype, hipStream_t stream);
 int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int t, int width, int causal, hipStream_t stream);
 int launch_im2col(const float* pixels, bf16_t* patches, int batch, int image_size, int patch, int kpad, hipStream_t stream);
 int launch_cls_rows(float* x, const float* class_emb, const float* pos, int batch, int tokens, int width, hipStream_t stream);
 int launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos, void* x, int x_dtype, int batch, int ctx,
                       int width, int vocab, hipStream_t stream);
 // pooled row -> LayerNorm -> @ proj [width, d] -> optional L2 normalise.  ids == nullptr: row = b * tokens (CLS)
-// delta (optional): the last block's pending residual update, added to the pooled row
-int launch_tail(const void* x, int x_dtype, const bf16_t* delta, const int32_t* ids, int batch, int tokens, int width, const float* gamma,
+// delta, delta2 (optional): the last block's pending residual updates, added to the pooled row
+int launch_tail(const void* x, int x_dtype, const bf16_t* delta, const bf16_t* delta2, const int32_t* ids, int batch, int tokens, int width, const float* gamma,
                 const float* beta, const float* proj, int d, int normalize, float* out, hipStream_t stream);
 
 }  // namespace kemr

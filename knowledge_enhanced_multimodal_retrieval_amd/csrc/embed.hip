@@ -118,7 +118,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // 4*jq..4*jq+3 over the rows i = g (mod 16) with 16-byte loads of the fp32 projection, then 4 shuffle steps.
 template <typename XT>
 __global__ __launch_bounds__(256) void tail_proj_kernel(const XT* __restrict__ x, const bf16_t* __restrict__ delta,
-                                                        const int32_t* __restrict__ ids,
+                                                        const bf16_t* __restrict__ delta2, const int32_t* __restrict__ ids,
                                                         int tokens, int width, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ proj,
                                                         int d, float* __restrict__ out) {
@@ -149,12 +149,14 @@ __global__ __launch_bounds__(256) void tail_proj_kernel(const XT* __restrict__ x
     const size_t prow = (size_t)b * tokens + *pool;
     const XT* xr = x + prow * width;
     const bf16_t* dr = delta ? delta + prow * width : nullptr;
+    const bf16_t* dr2 = delta2 ? delta2 + prow * width : nullptr;
 
     float s = 0.f;
     for (int i = tid; i < width; i += 256) {           // pooled row (+ the pending residual update) into LDS
         float v;
         if constexpr (sizeof(XT) == 4) v = xr[i]; else v = bf16_to_f32(xr[i]);
-        if (dr) v += bf16_to_f32(dr[i]);
+        if (dr) v += bf16_to_f32(dr[i]);       // same order as the fused LayerNorm updates: (x + d1) + d2
+        if (dr2) v += bf16_to_f32(dr2[i]);
         y[i] = v;
         s += v;
     }
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x,
     for (int i = lane; i < d; i += 64) r[i] *= inv;
 }
 
-int launch_tail(const void* x, int x_dtype, const bf16_t* delta, const int32_t* ids, int batch, int tokens, int width, const float* gamma,
+int launch_tail(const void* x, int x_dtype, const bf16_t* delta, const bf16_t* delta2, const int32_t* ids, int batch, int tokens, int width, const float* gamma,
                 const float* beta, const float* proj, int d, int normalize, float* out, hipStream_t stream) {
     if (batch <= 0) return KEMR_OK;
     if (d % 4 != 0 || d <= 0) KEMR_FAIL(KEMR_ERR_INVALID, "tail: embed_dim %d must be a positive multiple of 4", d);
@@ -205,9 +207,9 @@ int launch_tail(const void* x, int x_dtype, const bf16_t* delta, const int32_t* 
     ProfScope prof(PROF_OTHER, stream);
     const dim3 grid((d + 63) / 64, batch);
     if (x_dtype == KEMR_BF16)
-        hipLaunchKernelGGL(tail_proj_kernel<bf16_t>, grid, dim3(256), smem, stream, (const bf16_t*)x, delta, ids, tokens, width, gamma, beta, proj, d, out);
+        hipLaunchKernelGGL(tail_proj_kernel<bf16_t>, grid, dim3(256), smem, stream, (const bf16_t*)x, delta, delta2, ids, tokens, width, gamma, beta, proj, d, out);
     else
-        hipLaunchKernelGGL(tail_proj_kernel<float>, grid, dim3(256), smem, stream, (const float*)x, delta, ids, tokens, width, gamma, beta, proj, d, out);
+        hipLaunchKernelGGL(tail_proj_kernel<float>, grid, dim3(256), smem, stream, (const float*)x, delta, delta2, ids, tokens, width, gamma, beta, proj, d, out);
     KEMR_CHECK_LAUNCH("tail_proj_kernel");
     if (normalize) {
         hipLaunchKernelGGL(l2norm_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, stream, out, batch, d);

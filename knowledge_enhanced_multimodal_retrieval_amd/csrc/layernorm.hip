@@ -6,9 +6,13 @@
 
 namespace kemr {
 
-// RESID: the residual update of the preceding GEMM is fused here.  That GEMM stored its output (bias included) as a
-// bf16 "delta" (store-only epilogue, overlapped by the persistent GEMM kernel); this kernel computes x += delta, writes
-// the fp32 residual stream back and normalises the updated row: 4 + 2 bytes read, 4 + 2 written per element.
+// MODE: the residual updates of the preceding GEMMs are fused here.  Those GEMMs stored their outputs (bias included) as
+// bf16 "deltas" (store-only epilogues); this kernel adds them while it reads x anyway.
+//   MODE 1 (ln_1 of a block):  x += d1 (+ d2), written back, y = LN(x)    4 + 2 (+ 2) bytes read, 4 + 2 written per element
+//   MODE 2 (ln_2 of a block):  y = LN(x + d1), x NOT written back         4 + 2 read, 2 written: the attention delta d1
+//                              stays pending and is added for good, together with the MLP delta, by the next ln_1
+// (one x write per block instead of two; the sums are formed in the same order as two separate updates, so an fp32
+// stream holds bit-identical values).
 __device__ __forceinline__ float4 load_row4(const float* r, int i) { return ((const float4*)r)[i]; }
 __device__ __forceinline__ float4 load_row4(const bf16_t* r, int i) {
     const uint2 d = ((const uint2*)r)[i];
@@ -23,8 +27,8 @@ __device__ __forceinline__ void store_row4(bf16_t* r, int i, float4 v) {
     ((uint2*)r)[i] = pk;
 }
 
-template <int NV, typename XT, typename OutT, bool RESID>   // width = NV * 256
-__global__ __launch_bounds__(256) void layernorm_kernel(XT* x, const bf16_t* __restrict__ delta,
+template <int NV, typename XT, typename OutT, int MODE>   // width = NV * 256
+__global__ __launch_bounds__(256) void layernorm_kernel(XT* x, const bf16_t* __restrict__ delta, const bf16_t* __restrict__ delta2,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         OutT* y, int rows, float eps) {
     constexpr int W = NV * 256;
@@ -37,10 +41,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(XT* x, const bf16_t* __r
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         v[i] = load_row4(xr, i * 64 + lane);
-        if constexpr (RESID) {
+        if constexpr (MODE != 0) {
             const float4 d = load_row4(delta + (size_t)row * W, i * 64 + lane);
             v[i].x += d.x; v[i].y += d.y; v[i].z += d.z; v[i].w += d.w;
-            store_row4(xr, i * 64 + lane, v[i]);     // a bf16 stream rounds here; the statistics use the fp32 sum
+            if (MODE == 1 && delta2) {               // wave-uniform
+                const float4 e = load_row4(delta2 + (size_t)row * W, i * 64 + lane);
+                v[i].x += e.x; v[i].y += e.y; v[i].z += e.z; v[i].w += e.w;
+            }
+            if constexpr (MODE == 1) store_row4(xr, i * 64 + lane, v[i]);   // a bf16 stream rounds here; the statistics use the fp32 sum
         }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
@@ -66,42 +74,46 @@ __global__ __launch_bounds__(256) void layernorm_kernel(XT* x, const bf16_t* __r
 }
 
 template <int NV, typename XT>
-static int launch_nv(XT* x, const bf16_t* delta, const float* g, const float* b, void* y, int rows, int out_dtype,
-                     hipStream_t s) {
+static int launch_nv(XT* x, const bf16_t* d1, const bf16_t* d2, int writeback, const float* g, const float* b, void* y, int rows,
+                     int out_dtype, hipStream_t s) {
     const int blocks = (rows + 3) / 4;
     ProfScope prof(PROF_LAYERNORM, s);
-    if (delta)
-        hipLaunchKernelGGL((layernorm_kernel<NV, XT, bf16_t, true>), dim3(blocks), dim3(256), 0, s, x, delta, g, b, (bf16_t*)y, rows, 1e-5f);
+    if (d1 && writeback)
+        hipLaunchKernelGGL((layernorm_kernel<NV, XT, bf16_t, 1>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (bf16_t*)y, rows, 1e-5f);
+    else if (d1)
+        hipLaunchKernelGGL((layernorm_kernel<NV, XT, bf16_t, 2>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (bf16_t*)y, rows, 1e-5f);
     else if (out_dtype == KEMR_BF16)
-        hipLaunchKernelGGL((layernorm_kernel<NV, XT, bf16_t, false>), dim3(blocks), dim3(256), 0, s, x, delta, g, b, (bf16_t*)y, rows, 1e-5f);
+        hipLaunchKernelGGL((layernorm_kernel<NV, XT, bf16_t, 0>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (bf16_t*)y, rows, 1e-5f);
     else
-        hipLaunchKernelGGL((layernorm_kernel<NV, XT, float, false>), dim3(blocks), dim3(256), 0, s, x, delta, g, b, (float*)y, rows, 1e-5f);
+        hipLaunchKernelGGL((layernorm_kernel<NV, XT, float, 0>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (float*)y, rows, 1e-5f);
     KEMR_CHECK_LAUNCH("layernorm_kernel");
     return KEMR_OK;
 }
 
 template <typename XT>
-static int launch_xt(XT* x, const bf16_t* delta, const float* gamma, const float* beta, void* y, int rows, int width,
-                     int out_dtype, hipStream_t stream) {
+static int launch_xt(XT* x, const bf16_t* d1, const bf16_t* d2, int writeback, const float* gamma, const float* beta, void* y,
+                     int rows, int width, int out_dtype, hipStream_t stream) {
     switch (width) {
-        case 256:  return launch_nv<1>(x, delta, gamma, beta, y, rows, out_dtype, stream);
-        case 512:  return launch_nv<2>(x, delta, gamma, beta, y, rows, out_dtype, stream);
-        case 768:  return launch_nv<3>(x, delta, gamma, beta, y, rows, out_dtype, stream);
-        case 1024: return launch_nv<4>(x, delta, gamma, beta, y, rows, out_dtype, stream);
-        case 1280: return launch_nv<5>(x, delta, gamma, beta, y, rows, out_dtype, stream);
+        case 256:  return launch_nv<1>(x, d1, d2, writeback, gamma, beta, y, rows, out_dtype, stream);
+        case 512:  return launch_nv<2>(x, d1, d2, writeback, gamma, beta, y, rows, out_dtype, stream);
+        case 768:  return launch_nv<3>(x, d1, d2, writeback, gamma, beta, y, rows, out_dtype, stream);
+        case 1024: return launch_nv<4>(x, d1, d2, writeback, gamma, beta, y, rows, out_dtype, stream);
+        case 1280: return launch_nv<5>(x, d1, d2, writeback, gamma, beta, y, rows, out_dtype, stream);
     }
     KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: width %d not in {256,512,768,1024,1280}", width);
 }
 
-// x_dtype: KEMR_F32 or KEMR_BF16 rows.  delta != nullptr: x += delta first (x is updated in place; the output is bf16)
-int launch_layernorm(void* x, int x_dtype, const bf16_t* delta, const float* gamma, const float* beta, void* y, int rows,
-                     int width, int out_dtype, hipStream_t stream) {
+// x_dtype: KEMR_F32 or KEMR_BF16 rows.  delta != nullptr: LN(x + delta [+ delta2]); with `writeback` the sum replaces x
+// (delta2 needs writeback); the output is bf16 then.
+int launch_layernorm(void* x, int x_dtype, const bf16_t* delta, const bf16_t* delta2, int writeback, const float* gamma,
+                     const float* beta, void* y, int rows, int width, int out_dtype, hipStream_t stream) {
     if (rows <= 0) return KEMR_OK;
     if (out_dtype != KEMR_BF16 && out_dtype != KEMR_F32) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: bad out dtype %d", out_dtype);
     if (x_dtype != KEMR_BF16 && x_dtype != KEMR_F32) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: bad row dtype %d", x_dtype);
-    if (delta && out_dtype != KEMR_BF16) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: the residual form writes bf16");
-    if (x_dtype == KEMR_BF16) return launch_xt((bf16_t*)x, delta, gamma, beta, y, rows, width, out_dtype, stream);
-    return launch_xt((float*)x, delta, gamma, beta, y, rows, width, out_dtype, stream);
+    if (delta && out_dtype != KEMR_BF16) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: the residual forms write bf16");
+    if (delta2 && !(delta && writeback)) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: a second delta needs the first one and writeback");
+    if (x_dtype == KEMR_BF16) return launch_xt((bf16_t*)x, delta, delta2, writeback, gamma, beta, y, rows, width, out_dtype, stream);
+    return launch_xt((float*)x, delta, delta2, writeback, gamma, beta, y, rows, width, out_dtype, stream);
 }
 
 }  // namespace kemr

@@ -337,8 +337,9 @@ def op_layernorm_resid(x: torch.Tensor, delta: torch.Tensor, gamma: torch.Tensor
 
 
 def op_layernorm_rows(x: torch.Tensor, delta: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
-                      out_bf16: bool = True) -> torch.Tensor:
-    """General form: x is fp32 or bf16 rows; with `delta` (bf16) x += delta is written back in x's dtype first."""
+                      out_bf16: bool = True, delta2: Optional[torch.Tensor] = None, writeback: bool = True) -> torch.Tensor:
+    """General form: x is fp32 or bf16 rows; returns LayerNorm(x [+ delta [+ delta2]]) (deltas bf16); with `writeback`
+    the sum is stored back into x in x's dtype."""
     L = _lib.lib()
     rows, width = x.shape
     if x.dtype not in (torch.float32, torch.bfloat16):
@@ -346,7 +347,8 @@ def op_layernorm_rows(x: torch.Tensor, delta: Optional[torch.Tensor], gamma: tor
     y = torch.empty((rows, width), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(L.kemr_op_layernorm_rows(C.c_void_p(x.data_ptr()), _lib.KEMR_BF16 if x.dtype == torch.bfloat16 else _lib.KEMR_F32,
-                                            _opt_ptr(delta), C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()),
+                                            _opt_ptr(delta), _opt_ptr(delta2), 1 if writeback else 0,
+                                            C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()),
                                             C.c_void_p(y.data_ptr()), rows, width,
                                             _lib.KEMR_BF16 if out_bf16 else _lib.KEMR_F32,
                                             C.c_void_p(_stream_ptr(x.device))), "op_layernorm_rows")

@@ -50,7 +50,7 @@ def test_model_create_validates_config():
     n = lib.kemr_model_num_tensors(h)
     names = [lib.kemr_model_tensor_name(h, i).decode() for i in range(n)]
     assert n == 13 + 2 * 2 * 12 and "visual.transformer.resblocks.1.mlp.c_proj.weight" in names
-    assert lib.kemr_workspace_bytes(h, _lib.TOWER_VISION, 3) == 256 * 256 * 16    # 51 tokens -> 256 rows x 16 B x width
+    assert lib.kemr_workspace_bytes(h, _lib.TOWER_VISION, 3) == 256 * 256 * 18    # 51 tokens -> 256 rows x 18 B x width (x f32, h, 2 deltas, 4W big)
     lib.kemr_model_destroy(h)
     for bad in (dict(v_width=200), dict(image_size=30), dict(embed_dim=0), dict(ctx=400), dict(patch=0)):
         h2 = C.c_void_p()

@@ -202,10 +202,35 @@ def test_layernorm_bf16_rows(device, width):
     assert float((y32.cpu() - ref).abs().max()) < 2e-5
     L = _lib.lib()
     import ctypes as C
-    _lib.check(L.kemr_op_layernorm_rows(C.c_void_p(xd.data_ptr()), _lib.KEMR_BF16, None, C.c_void_p(gd.data_ptr()),
+    _lib.check(L.kemr_op_layernorm_rows(C.c_void_p(xd.data_ptr()), _lib.KEMR_BF16, None, None, 0, C.c_void_p(gd.data_ptr()),
                                         C.c_void_p(bd.data_ptr()), C.c_void_p(xd.data_ptr()), rows, width, _lib.KEMR_BF16, None))
     torch.cuda.synchronize()
     assert float((xd.float().cpu() - ref).abs().max()) < 4e-2
+
+
+@pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
+def test_layernorm_two_pending_deltas(device, xdt):
+    """ln_2 form: LN(x + d1) without touching x; next ln_1 form: x += d1 + d2 written back once -- equal to two updates."""
+    width, rows = 1024, 301
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(rows, width, generator=g) * 2).to(xdt)
+    d1 = (torch.randn(rows, width, generator=g) * 0.5).to(torch.bfloat16)
+    d2 = (torch.randn(rows, width, generator=g) * 0.5).to(torch.bfloat16)
+    gamma, beta = 1 + 0.1 * torch.randn(width, generator=g), 0.1 * torch.randn(width, generator=g)
+    gd, bd = gamma.to(device), beta.to(device)
+    xd = x.clone().to(device)
+    y2 = engine.op_layernorm_rows(xd, d1.to(device), gd, bd, writeback=False)
+    torch.cuda.synchronize()
+    assert torch.equal(xd.cpu(), x)                                                   # untouched
+    ref2 = torch.nn.functional.layer_norm(x.float() + d1.float(), (width,), gamma, beta, 1e-5)
+    assert float((y2.float().cpu() - ref2).abs().max()) < 2e-2
+    y1 = engine.op_layernorm_rows(xd, d1.to(device), gd, bd, delta2=d2.to(device))
+    torch.cuda.synchronize()
+    xs = (x.float() + d1.float()) + d2.float()                                       # same association as two updates
+    assert torch.equal(xd.cpu(), xs.to(xdt))
+    assert float((y1.float().cpu() - torch.nn.functional.layer_norm(xs, (width,), gamma, beta, 1e-5)).abs().max()) < 2e-2
+    with pytest.raises(RuntimeError, match="second delta"):
+        engine.op_layernorm_rows(xd, d1.to(device), gd, bd, delta2=d2.to(device), writeback=False)
 
 
 def _attention_ref(qkv, batch, t, width, causal):
