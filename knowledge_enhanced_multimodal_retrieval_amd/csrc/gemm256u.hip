@@ -84,6 +84,11 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
         col0 = (L - tm * tiles_n) << 8;
     };
     const int nt = p.K >> 6;
+    // Order of the three pieces of K-tile g+1 staged during K-tile g.  Long K (fc2: A is the 0.5 GB MLP hidden, streamed
+    // from HBM, 4 tiles per A panel): the A halves first, a full K-tile ahead of their use, then W1 (measured, sustained:
+    // 470 -> 443 us at K = 4096).  Short K (A panels shared by 12-16 column tiles, mostly L2 hits): W1, A0, A1 spread over
+    // the first three intervals is 1 % faster.
+    const bool afirst = nt >= 32;
 
     // staging addresses = wave-uniform K-tile base (SGPRs) + a per-lane 32-bit byte offset that never changes
     const int srow = lane >> 3, schunk = lane & 7;
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
                 af[mi][0] = *(const bf16x8*)(sa + mi * 2048 + co0);
                 af[mi][1] = *(const bf16x8*)(sa + mi * 2048 + co1);
             }
-            if (c1.valid) stage_w(1, c1);
+            if (c1.valid) { if (afirst) { stage_a(0, c1); stage_a(1, c1); } else stage_w(1, c1); }
             __builtin_amdgcn_s_barrier();
             quad<0, 0>(acc, af, w0);
             __builtin_amdgcn_s_barrier();
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
                 w1[ni][0] = *(const bf16x8*)(sb + 4096 + ni * 2048 + co0);
                 w1[ni][1] = *(const bf16x8*)(sb + 4096 + ni * 2048 + co1);
             }
-            if (c1.valid) stage_a(0, c1);
+            if (c1.valid) { if (afirst) stage_w(1, c1); else stage_a(0, c1); }
             __builtin_amdgcn_s_barrier();
             quad<0, 1>(acc, af, w1);
             __builtin_amdgcn_s_barrier();
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
                 af[mi][0] = *(const bf16x8*)(sa + 8192 + mi * 2048 + co0);
                 af[mi][1] = *(const bf16x8*)(sa + 8192 + mi * 2048 + co1);
             }
-            if (c1.valid) stage_a(1, c1);
+            if (c1.valid && !afirst) stage_a(1, c1);
             __builtin_amdgcn_s_barrier();
             quad<1, 1>(acc, af, w1);
             __builtin_amdgcn_s_barrier();
@@ -254,6 +259,8 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             // of a launch evicts the A / W panels the K loops live on from L2 (measured on the encoder shapes: plain stores
             // +27 % time on QKV, +17 % on fc1 over no stores at all; `nt` stores +0 % / +6 %; `sc1` write-through +13 %;
             // the same stores aimed at an L2-resident 8 MiB cost nothing, so the instruction issue is not the price).
+            // Inside the encoder chain (bench.py, same device): all four block GEMMs with plain stores 13 490 items/s,
+            // all non-temporal 14 065; every one of the four contributes, the LayerNorm reading the deltas included.
             // Inline asm because __builtin_nontemporal_store did not produce this encoding; 2 stores per lane and pass,
             // the vmcnt bookkeeping in the header counts them.
             if (!(p.dbg & 1) && !((p.dbg & 32) && mi >= 4)) {          // dbg 1 / 32: TIMING ONLY, all / half the stores dropped
