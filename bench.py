@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=255, help="gallery items per rank per step")
     ap.add_argument("--model", default="ViT-L/14")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16-res16"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16-res16", "fp8", "fp8-mlp"],
                     help="bf16 operands with an fp32 (default) or bf16 residual stream")
     ap.add_argument("--gemm-variant", type=int, default=0, help="A/B only: force a GEMM tile variant (0 = the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -179,7 +179,7 @@ def main():
         "metric": "gallery images+texts encoded/sec (ViT-L/14) and 43k x Q sim+top-10 ms",
         "value": value, "unit": "items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": {"fp8": "fp8 (QKV) + bf16", "fp8-mlp": "fp8 (QKV, fc1) + bf16"}.get(args.precision, "bf16"), "data": "synthetic",
         "config": {"workload": "CLIP ViT-L/14 zero-shot: 43k-gallery encode (1 image + query + target text per item, "
                                "224x224 / 77 tokens) + T2I top-10, BASELINE configs[1]",
                    "model": args.model, "residual_stream": "bf16" if args.precision == "bf16-res16" else "fp32", "batch_per_gpu": B, "gallery": GALLERY, "parallelism": f"dp{world} (gallery sharded)"},

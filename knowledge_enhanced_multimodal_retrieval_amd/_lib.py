@@ -15,10 +15,12 @@ import threading
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libkemr.so")
 
-KEMR_F32, KEMR_BF16, KEMR_I32 = 0, 1, 2
+KEMR_F32, KEMR_BF16, KEMR_I32, KEMR_FP8 = 0, 1, 2, 3
 PREC_BF16 = 1
 PREC_BF16_RES16 = 2
-PRECISIONS = {"bf16": PREC_BF16, "bf16-res16": PREC_BF16_RES16}
+PREC_FP8 = 3
+PREC_FP8_MLP = 4
+PRECISIONS = {"bf16": PREC_BF16, "bf16-res16": PREC_BF16_RES16, "fp8": PREC_FP8, "fp8-mlp": PREC_FP8_MLP}
 TOWER_VISION, TOWER_TEXT = 0, 1
 SIDE_QUERY, SIDE_GALLERY = 0, 1
 EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RESID_F32 = 0, 1, 2
@@ -58,6 +60,8 @@ SIGNATURES = {
     "kemr_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i64), _i]),
     "kemr_set_gemm_variant": (_i, [_i]),
     "kemr_op_gemm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "kemr_op_gemm_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "kemr_op_e4m3_host": (_i, [_vp, _vp, C.c_longlong]),
     "kemr_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "kemr_op_layernorm_resid": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "kemr_op_layernorm_rows": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -2,6 +2,7 @@
 // Host-side C++ only; every kernel lives in gemm.hip / layernorm.hip / attention.hip / embed.hip / sim.hip.
 #include "common.h"
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -47,6 +48,9 @@ struct HostTensor {
 struct LayerW {
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *bqkv, *bo, *b1, *b2;
     const bf16_t *wqkv, *wo, *w1, *w2;
+    // KEMR_PREC_FP8: e4m3 copies of wqkv / w1 (instead of the bf16 ones) and their per-output-channel scales
+    const uint8_t *wqkv8 = nullptr, *w18 = nullptr;
+    const float *sqkv = nullptr, *s1 = nullptr;
 };
 
 struct TowerW {
@@ -67,6 +71,7 @@ struct kemr_model {
     size_t arena_bytes = 0;
     int grid = 0, patches = 0, kpad = 0;
     int res_dtype = KEMR_F32;                       // storage type of the residual stream (KEMR_PREC_BF16_RES16: bf16)
+    int fp8 = 0;                                    // bit 0: QKV on fp8 operands (KEMR_PREC_FP8), bit 1: fc1 too (KEMR_PREC_FP8_MLP)
     // vision
     TowerW vis;
     const bf16_t* conv_w = nullptr;
@@ -185,8 +190,11 @@ extern "C" int kemr_model_load_tensor(kemr_model* m, const char* name, const voi
 
 extern "C" int kemr_model_finalize(kemr_model* m, int precision) {
     if (!m) KEMR_FAIL(KEMR_ERR_INVALID, "finalize: null model");
-    if (precision != KEMR_PREC_BF16 && precision != KEMR_PREC_BF16_RES16)
+    if (precision < KEMR_PREC_BF16 || precision > KEMR_PREC_FP8_MLP)
         KEMR_FAIL(KEMR_ERR_INVALID, "finalize: unsupported precision %d", precision);
+    const int fp8 = precision == KEMR_PREC_FP8 ? 1 : precision == KEMR_PREC_FP8_MLP ? 3 : 0;
+    if (fp8 && ((m->cfg.v_width % 128) || (m->cfg.t_width % 128) || m->cfg.v_width < 256 || m->cfg.t_width < 256))
+        KEMR_FAIL(KEMR_ERR_INVALID, "finalize: fp8 needs tower widths that are multiples of 128 and >= 256");
     for (const auto& n : m->names)
         if (!m->tensors[n].loaded) KEMR_FAIL(KEMR_ERR_STATE, "finalize: missing key '%s' (strict load)", n.c_str());
 
@@ -198,10 +206,14 @@ extern "C" int kemr_model_finalize(kemr_model* m, int precision) {
                n.find("c_fc.weight") != std::string::npos || n.find("c_proj.weight") != std::string::npos ||
                n == "visual.conv1.weight";
     };
+    auto is_fp8_matrix = [&](const std::string& n) {
+        return ((fp8 & 1) && n.find("in_proj_weight") != std::string::npos) || ((fp8 & 2) && n.find("c_fc.weight") != std::string::npos);
+    };
     for (const auto& n : m->names) {
         const HostTensor& t = m->tensors[n];
         size_t bytes;
         if (n == "visual.conv1.weight") bytes = (size_t)m->cfg.v_width * m->kpad * 2;
+        else if (is_fp8_matrix(n)) { bytes = t.data.size(); off[n + "#scale"] = plan.take((size_t)t.shape[0] * 4); }
         else if (is_matrix(n)) bytes = t.data.size() * 2;
         else bytes = t.data.size() * 4;
         off[n] = plan.take(bytes);
@@ -215,6 +227,20 @@ extern "C" int kemr_model_finalize(kemr_model* m, int precision) {
             bf16_t* d = (bf16_t*)dst;
             for (int r = 0; r < m->cfg.v_width; ++r)
                 for (int k = 0; k < kv; ++k) d[(size_t)r * m->kpad + k] = f32_to_bf16_host(t.data[(size_t)r * kv + k]);
+        } else if (is_fp8_matrix(n)) {
+            // e4m3 with one scale per output channel (row): scale = amax / 448; the attention scale 1/8 goes into the q rows
+            const int64_t rows = t.shape[0], cols = t.shape[1];
+            const bool qkv = n.find("in_proj_weight") != std::string::npos;
+            uint8_t* d = (uint8_t*)dst;
+            float* sc = (float*)(host.data() + off[n + "#scale"]);
+            for (int64_t r = 0; r < rows; ++r) {
+                const float pre = (qkv && r < cols) ? 0.125f : 1.0f;
+                float amax = 0.f;
+                for (int64_t c = 0; c < cols; ++c) amax = fmaxf(amax, fabsf(t.data[r * cols + c] * pre));
+                const float scale = amax > 0.f ? amax / 448.f : 1.0f;
+                sc[r] = scale;
+                for (int64_t c = 0; c < cols; ++c) d[r * cols + c] = f32_to_e4m3_host(t.data[r * cols + c] * pre / scale);
+            }
         } else if (n.find("in_proj_weight") != std::string::npos) {
             // fold the attention scale 1/sqrt(64) = 0.125 (exact in bf16) into the query rows
             const int64_t w = t.shape[1];
@@ -250,9 +276,11 @@ extern "C" int kemr_model_finalize(kemr_model* m, int precision) {
             LayerW& L = tw.layer[i];
             L.ln1_g = F(b + ".ln_1.weight"); L.ln1_b = F(b + ".ln_1.bias");
             L.wqkv = H(b + ".attn.in_proj_weight"); L.bqkv = F(b + ".attn.in_proj_bias");
+            if (fp8 & 1) { L.wqkv8 = (const uint8_t*)L.wqkv; L.wqkv = nullptr; L.sqkv = F(b + ".attn.in_proj_weight#scale"); }
+            if (fp8 & 2) { L.w18 = (const uint8_t*)H(b + ".mlp.c_fc.weight"); L.s1 = F(b + ".mlp.c_fc.weight#scale"); }
             L.wo = H(b + ".attn.out_proj.weight"); L.bo = F(b + ".attn.out_proj.bias");
             L.ln2_g = F(b + ".ln_2.weight"); L.ln2_b = F(b + ".ln_2.bias");
-            L.w1 = H(b + ".mlp.c_fc.weight"); L.b1 = F(b + ".mlp.c_fc.bias");
+            L.w1 = (fp8 & 2) ? nullptr : H(b + ".mlp.c_fc.weight"); L.b1 = F(b + ".mlp.c_fc.bias");
             L.w2 = H(b + ".mlp.c_proj.weight"); L.b2 = F(b + ".mlp.c_proj.bias");
         }
     };
@@ -268,6 +296,7 @@ extern "C" int kemr_model_finalize(kemr_model* m, int precision) {
 
     for (auto& kv : m->tensors) { std::vector<float>().swap(kv.second.data); kv.second.loaded = false; }
     m->res_dtype = precision == KEMR_PREC_BF16_RES16 ? KEMR_BF16 : KEMR_F32;
+    m->fp8 = fp8;
     m->finalized = true;
     return KEMR_OK;
 }
@@ -318,22 +347,35 @@ int carve(Workspace& w, void* base, size_t bytes, int width, int tokens, int bat
 // as bf16 into `delta` / `delta2` (store-only epilogues) and the LayerNorms apply the updates while they read x anyway:
 // ln_2 normalises x + delta without writing x; the next block's ln_1 writes x += delta + delta2 once and normalises it.
 // On return both deltas of the last block are still pending; the caller's tail adds them.
-int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, hipStream_t s) {
+int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, int fp8, hipStream_t s) {
     const int W = t.width, M = batch * t.tokens;
+    const bool fq = fp8 & 1, f1 = fp8 & 2;          // LayerNorm output = A operand of QKV / fc1: e4m3 where that GEMM runs in fp8
     for (int l = 0; l < t.layers; ++l) {
         const LayerW& L = t.layer[l];
-        KEMR_TRY(launch_layernorm(w.x, w.x_dtype, l ? w.delta : nullptr, l ? w.delta2 : nullptr, 1, L.ln1_g, L.ln1_b, w.h, M, W, KEMR_BF16, s));
+        KEMR_TRY(launch_layernorm(w.x, w.x_dtype, l ? w.delta : nullptr, l ? w.delta2 : nullptr, 1, L.ln1_g, L.ln1_b, w.h, M, W, fq ? KEMR_FP8 : KEMR_BF16, s));
         GemmParams g{};
         g.M = M;
         g.c_rows_padded = 1;       // every workspace buffer has ceil256(M) rows
         g.A = w.h; g.lda = W; g.W = L.wqkv; g.ldw = W; g.bias = L.bqkv; g.C = w.big; g.ldc = 3 * W; g.N = 3 * W; g.K = W;
-        KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+        if (fq) {
+            g.W = (const bf16_t*)L.wqkv8; g.wscale = L.sqkv;
+            KEMR_TRY(launch_gemm256u_fp8(g, EPI_BIAS_BF16, s));
+            g.wscale = nullptr;
+        } else {
+            KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+        }
         KEMR_TRY(launch_attention(w.big, w.h, batch, t.tokens, W, causal, s));
         g.A = w.h; g.lda = W; g.W = L.wo; g.ldw = W; g.bias = L.bo; g.C = w.delta; g.ldc = W; g.N = W; g.K = W;
         KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
-        KEMR_TRY(launch_layernorm(w.x, w.x_dtype, w.delta, nullptr, 0, L.ln2_g, L.ln2_b, w.h, M, W, KEMR_BF16, s));
+        KEMR_TRY(launch_layernorm(w.x, w.x_dtype, w.delta, nullptr, 0, L.ln2_g, L.ln2_b, w.h, M, W, f1 ? KEMR_FP8 : KEMR_BF16, s));
         g.A = w.h; g.lda = W; g.W = L.w1; g.ldw = W; g.bias = L.b1; g.C = w.big; g.ldc = 4 * W; g.N = 4 * W; g.K = W;
-        KEMR_TRY(launch_gemm(g, EPI_BIAS_QGELU_BF16, s));
+        if (f1) {
+            g.W = (const bf16_t*)L.w18; g.wscale = L.s1;
+            KEMR_TRY(launch_gemm256u_fp8(g, EPI_BIAS_QGELU_BF16, s));
+            g.wscale = nullptr;
+        } else {
+            KEMR_TRY(launch_gemm(g, EPI_BIAS_QGELU_BF16, s));
+        }
         g.A = w.big; g.lda = 4 * W; g.W = L.w2; g.ldw = 4 * W; g.bias = L.b2; g.C = w.delta2; g.ldc = W; g.N = W; g.K = 4 * W;
         KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
     }
@@ -366,7 +408,7 @@ extern "C" int kemr_encode_image(kemr_model* m, const float* pixels_dev, int bat
     KEMR_TRY(launch_gemm(g, EPI_PATCH_F32, s));
     KEMR_TRY(launch_cls_rows(w.x32, m->cls, m->vpos, batch, T, W, s));
     KEMR_TRY(launch_layernorm(w.x32, KEMR_F32, nullptr, nullptr, 0, m->lnpre_g, m->lnpre_b, w.x, batch * T, W, w.x_dtype, s));
-    KEMR_TRY(run_blocks(m->vis, w, batch, 0, s));
+    KEMR_TRY(run_blocks(m->vis, w, batch, 0, m->fp8, s));
     const bool vb = m->vis.layers > 0;
     KEMR_TRY(launch_tail(w.x, w.x_dtype, vb ? w.delta : nullptr, vb ? w.delta2 : nullptr, nullptr, batch, T, W, m->lnpost_g, m->lnpost_b, m->vproj, m->cfg.embed_dim, normalize, out_dev, s));
     return KEMR_OK;
@@ -383,7 +425,7 @@ extern "C" int kemr_encode_text(kemr_model* m, const int32_t* ids_dev, int batch
     Workspace w;
     KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, T, batch, m->res_dtype));
     KEMR_TRY(launch_text_embed(ids_dev, m->tok, m->tpos, w.x, w.x_dtype, batch, T, W, m->cfg.vocab, s));
-    KEMR_TRY(run_blocks(m->txt, w, batch, 1, s));
+    KEMR_TRY(run_blocks(m->txt, w, batch, 1, m->fp8, s));
     const bool tb = m->txt.layers > 0;
     KEMR_TRY(launch_tail(w.x, w.x_dtype, tb ? w.delta : nullptr, tb ? w.delta2 : nullptr, ids_dev, batch, T, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s));
     return KEMR_OK;
@@ -437,6 +479,22 @@ extern "C" int kemr_op_gemm(const void* a_dev, const void* w_dev, const float* b
     g.M = m; g.N = n; g.K = k;
     g.c_rows_padded = 1;           // documented requirement of this entry point: C (like A) has ceil256(m) rows
     return launch_gemm(g, epilogue, (hipStream_t)stream);
+}
+
+extern "C" int kemr_op_gemm_fp8(const void* a_dev, const void* w_dev, const float* wscale_dev, const float* bias_dev, void* c_dev,
+                                int m, int n, int k, int epilogue, void* stream) {
+    if (!a_dev || !w_dev || !wscale_dev || !c_dev) KEMR_FAIL(KEMR_ERR_INVALID, "op_gemm_fp8: null argument");
+    GemmParams g{};
+    g.A = (const bf16_t*)a_dev; g.lda = k; g.W = (const bf16_t*)w_dev; g.ldw = k; g.bias = bias_dev; g.wscale = wscale_dev;
+    g.C = c_dev; g.ldc = n; g.M = m; g.N = n; g.K = k;
+    g.c_rows_padded = 1;
+    return launch_gemm256u_fp8(g, epilogue, (hipStream_t)stream);
+}
+
+extern "C" int kemr_op_e4m3_host(const float* in, unsigned char* out, long long n) {
+    if (!in || !out || n < 0) KEMR_FAIL(KEMR_ERR_INVALID, "op_e4m3_host: bad argument");
+    for (long long i = 0; i < n; ++i) out[i] = f32_to_e4m3_host(in[i]);
+    return KEMR_OK;
 }
 
 extern "C" int kemr_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, void* y_dev, int rows,

@@ -30,6 +30,26 @@ static inline uint16_t f32_to_bf16_host(float f) {
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);                 // round to nearest even
 }
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+// fp32 -> OCP fp8 e4m3fn (1-4-3, bias 7, max 448, no inf), round to nearest even, saturating; NaN -> 0x7f
+static inline uint8_t f32_to_e4m3_host(float f) {
+    if (f != f) return 0x7f;
+    const uint8_t sign = f < 0 ? 0x80 : 0;
+    float a = f < 0 ? -f : f;
+    if (a >= 448.f) return sign | 0x7e;
+    if (a < 0.0009765625f) return sign;                     // below half of the smallest subnormal (2^-9): zero
+    int e;
+    (void)__builtin_frexpf(a, &e);                          // a = m * 2^e, m in [0.5, 1)  ->  floor(log2 a) = e - 1
+    e -= 1;
+    if (e < -6) {                                           // subnormal: multiples of 2^-9
+        const float q = a * 512.f;
+        int m = (int)__builtin_nearbyintf(q);               // default rounding mode = nearest even
+        return sign | (uint8_t)m;                           // m == 8 is the smallest normal 0x08
+    }
+    int m = (int)__builtin_nearbyintf(__builtin_ldexpf(a, 3 - e));      // in [8, 16]
+    if (m == 16) { m = 8; e += 1; }
+    if (e > 8 || (e == 8 && m > 14)) return sign | 0x7e;
+    return sign | (uint8_t)(((e + 7) << 3) | (m - 8));
+}
 
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
@@ -79,6 +99,7 @@ struct GemmParams {
     const bf16_t* A;     // [m_alloc, lda] bf16, K contiguous
     const bf16_t* W;     // [N, ldw] bf16, K contiguous (PyTorch Linear layout)
     const float* bias;   // [N] or nullptr
+    const float* wscale; // fp8 operands only: [N] per-output-channel scale applied to the accumulators before the bias
     void* C;             // bf16 [m_alloc, ldc] or fp32 [*, ldc] depending on the epilogue
     const float* pos;    // EPI_PATCH_F32: positional embedding [1 + patches, N]
     int M, N, K;         // M = valid rows (stores are guarded), N % 128 == 0, K % 64 == 0
@@ -93,6 +114,7 @@ int launch_gemm256(const GemmParams& p, int epi, hipStream_t stream);   // gemm2
 int launch_gemm256p(const GemmParams& p, int epi, hipStream_t stream);  // gemm256p.hip: persistent, async epilogue (bf16-store epilogues)
 int launch_gemm256q(const GemmParams& p, int epi, hipStream_t stream);  // gemm256q.hip: persistent, 2 long phases per K-tile
 int launch_gemm256u(const GemmParams& p, int epi, hipStream_t stream);  // gemm256u.hip: gemm256p's K loop, one K-tile pipeline across tiles
+int launch_gemm256u_fp8(const GemmParams& p, int epi, hipStream_t stream);  // gemm256u.hip: fp8 e4m3 operands (A, W in bytes), bf16 C
 int launch_gemm256w(const GemmParams& p, int epi, hipStream_t stream);  // gemm256w.hip: persistent, 4 waves x 128x128 (AGPR accumulators)
 extern int g_gemm_variant;   // 0 auto, 1 = 128x128 (gemm.hip), 2 / 3 = 256x256 lockstep / staggered, 4 = persistent 256x256 (bf16 epilogues)
 

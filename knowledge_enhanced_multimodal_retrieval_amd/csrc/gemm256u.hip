@@ -20,7 +20,8 @@ constexpr int PBUF = 65536;      // bytes per K-tile buffer
 constexpr int PHALF = 16384;     // bytes per half-tile
 constexpr int PEPI = 131072;     // offset of the epilogue area (8 waves x 2 KiB)
 constexpr int PBIAS = PEPI + 16384;   // 2 x 1 KiB: fp32 bias of the current / next tile's 256 columns
-constexpr int PSMEM = PBIAS + 2048;
+constexpr int PSCALE = PBIAS + 2048;  // fp8 operands: 2 x 1 KiB per-output-channel weight scales of the current / next tile
+constexpr int PSMEM = PSCALE + 2048;
 
 __device__ __forceinline__ void glds16u(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -61,10 +62,30 @@ __device__ __forceinline__ void quad(f32x4 (&acc)[8][4], const bf16x8 (&af)[4][2
     __builtin_amdgcn_s_setprio(0);
 }
 
+// fp8 (OCP e4m3) operands: one block-scaled MFMA covers K = 128 (a lane holds 32 consecutive k bytes of its row), at twice
+// the bf16 MFMA's cycles, i.e. twice the FLOP rate; the E8M0 block scales are all 2^0 (0x7f), the real scales (one per
+// output channel of W) are applied in the epilogue.  A K-tile is still 128 bytes per row: staging, LDS image and swizzle
+// are the bf16 kernel's, a fragment is two adjacent 16-byte chunks instead of one.
+typedef __attribute__((ext_vector_type(8))) int fp8x32;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+template <int MH, int NH>
+__device__ __forceinline__ void quad8(f32x4 (&acc)[8][4], const fp8x32 (&af)[4], const fp8x32 (&wf)[2], int one) {
+    __builtin_amdgcn_s_setprio(1);
+    asm volatile("s_nop 1" ::: "memory");
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+            asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
+                         : "+v"(acc[MH * 4 + mi][NH * 2 + ni]) : "v"(wf[ni]), "v"(af[mi]), "v"(one));
+    __builtin_amdgcn_s_setprio(0);
+}
+
 }  // namespace
 
-template <int EPI>
+template <int EPI, bool FP8>
 __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmParams p) {
+    constexpr int ES = FP8 ? 1 : 2;          // operand element size
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
         row0 = tm << 8;
         col0 = (L - tm * tiles_n) << 8;
     };
-    const int nt = p.K >> 6;
+    const int nt = FP8 ? p.K >> 7 : p.K >> 6;      // K-tile = 128 bytes per row
     // Order of the three pieces of K-tile g+1 staged during K-tile g.  Long K (fc2: A is the 0.5 GB MLP hidden, streamed
     // from HBM, 4 tiles per A panel): the A halves first, a full K-tile ahead of their use, then W1 (measured, sustained:
     // 470 -> 443 us at K = 4096).  Short K (A panels shared by 12-16 column tiles, mostly L2 hits): W1, A0, A1 spread over
@@ -93,11 +114,11 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     // staging addresses = wave-uniform K-tile base (SGPRs) + a per-lane 32-bit byte offset that never changes
     const int srow = lane >> 3, schunk = lane & 7;
     const int r0 = wid * 16 + srow, r1 = r0 + 8;
-    const unsigned a_lane0 = (unsigned)(r0 * p.lda + ((schunk ^ ((r0 >> 1) & 7)) << 3)) * 2u;
-    const unsigned a_lane1 = (unsigned)(r1 * p.lda + ((schunk ^ ((r1 >> 1) & 7)) << 3)) * 2u;
-    const unsigned w_lane0 = (unsigned)(r0 * p.ldw + ((schunk ^ ((r0 >> 1) & 7)) << 3)) * 2u;
-    const unsigned w_lane1 = (unsigned)(r1 * p.ldw + ((schunk ^ ((r1 >> 1) & 7)) << 3)) * 2u;
-    const size_t a_half = (size_t)256 * p.lda, w_half = (size_t)256 * p.ldw;      // bytes between the two half-tiles
+    const unsigned a_lane0 = (unsigned)(r0 * p.lda * ES + ((schunk ^ ((r0 >> 1) & 7)) << 4));
+    const unsigned a_lane1 = (unsigned)(r1 * p.lda * ES + ((schunk ^ ((r1 >> 1) & 7)) << 4));
+    const unsigned w_lane0 = (unsigned)(r0 * p.ldw * ES + ((schunk ^ ((r0 >> 1) & 7)) << 4));
+    const unsigned w_lane1 = (unsigned)(r1 * p.ldw * ES + ((schunk ^ ((r1 >> 1) & 7)) << 4));
+    const size_t a_half = (size_t)128 * p.lda * ES, w_half = (size_t)128 * p.ldw * ES;      // bytes between the two half-tiles
     char* const stage_base = smem + wid * 2048;
 
     // a K-tile of the workgroup's tile sequence (all wave-uniform)
@@ -105,8 +126,8 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     auto cur_set = [&](Cur& c) {
         int row0, col0;
         tile_of(c.idx, row0, col0);
-        c.a = (const char*)p.A + (size_t)row0 * p.lda * 2;
-        c.w = (const char*)p.W + (size_t)col0 * p.ldw * 2;
+        c.a = (const char*)p.A + (size_t)row0 * p.lda * ES;
+        c.w = (const char*)p.W + (size_t)col0 * p.ldw * ES;
         c.col0 = col0;
     };
     auto cur_next = [&](Cur& c) {
@@ -133,12 +154,14 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     };
     auto stage_w0 = [&](const Cur& c) {       // first piece of a K-tile; with K-tile 0 of a tile: that tile's bias (wave 0)
         if (c.tau == 0 && wid == 0 && p.bias) glds16u(p.bias + c.col0 + lane * 4, smem + PBIAS + (c.seq & 1) * 1024);
+        if (FP8 && c.tau == 0 && wid == 0) glds16u(p.wscale + c.col0 + lane * 4, smem + PSCALE + (c.seq & 1) * 1024);
         stage_w(0, c);
     };
 
     const int lrow = lane & 15, lq = lane >> 4;
     const int swz = lrow >> 1;
-    const int co0 = ((0 + lq) ^ swz) << 4, co1 = ((4 + lq) ^ swz) << 4;
+    // bf16: fragments of the two 32-wide k steps (chunks lq and 4 + lq); fp8: the two halves of ONE 32-byte fragment
+    const int co0 = ((FP8 ? 2 * lq : lq) ^ swz) << 4, co1 = ((FP8 ? 2 * lq + 1 : 4 + lq) ^ swz) << 4;
     const int a_off = wr * PHALF + lrow * 128;
     const int b_off = 2 * PHALF + (wc >> 1) * PHALF + ((wc & 1) * 64 + lrow) * 128;
 
@@ -157,7 +180,34 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     if (wr == 1) __builtin_amdgcn_s_barrier();      // wr == 1 half runs one interval behind for the whole launch
 
     int gpar = 0, seq = 0;
-    bf16x8 af[4][2], w0[2][2], w1[2][2];
+    bf16x8 af[4][2], w0[2][2], w1[2][2];          // bf16 operands
+    fp8x32 af8[4], w08[2], w18[2];                 // fp8 operands (only one set is live, by FP8)
+    int one = 0x7f7f7f7f;                          // E8M0 block scales 2^0
+    asm volatile("" : "+v"(one));
+    auto ld_w = [&](bf16x8 (&w)[2][2], fp8x32 (&w8)[2], const char* q) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            if constexpr (FP8) {
+                w8[ni].lo = *(const i32x4*)(q + ni * 2048 + co0);
+                w8[ni].hi = *(const i32x4*)(q + ni * 2048 + co1);
+            } else {
+                w[ni][0] = *(const bf16x8*)(q + ni * 2048 + co0);
+                w[ni][1] = *(const bf16x8*)(q + ni * 2048 + co1);
+            }
+        }
+    };
+    auto ld_a = [&](const char* q) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            if constexpr (FP8) {
+                af8[mi].lo = *(const i32x4*)(q + mi * 2048 + co0);
+                af8[mi].hi = *(const i32x4*)(q + mi * 2048 + co1);
+            } else {
+                af[mi][0] = *(const bf16x8*)(q + mi * 2048 + co0);
+                af[mi][1] = *(const bf16x8*)(q + mi * 2048 + co1);
+            }
+        }
+    };
     for (int idx = blockIdx.x; idx < ntiles; idx += gridDim.x, ++seq) {
         f32x4 acc[8][4];
 #pragma unroll
@@ -171,37 +221,21 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
         for (int t = 0; t < nt; ++t, gpar ^= 1) {
             const char* sa = smem + gpar * PBUF + a_off;
             const char* sb = smem + gpar * PBUF + b_off;
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                w0[ni][0] = *(const bf16x8*)(sb + ni * 2048 + co0);
-                w0[ni][1] = *(const bf16x8*)(sb + ni * 2048 + co1);
-            }
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                af[mi][0] = *(const bf16x8*)(sa + mi * 2048 + co0);
-                af[mi][1] = *(const bf16x8*)(sa + mi * 2048 + co1);
-            }
+            ld_w(w0, w08, sb);
+            ld_a(sa);
             if (c1.valid) { if (afirst) { stage_a(0, c1); stage_a(1, c1); } else stage_w(1, c1); }
             __builtin_amdgcn_s_barrier();
-            quad<0, 0>(acc, af, w0);
+            if constexpr (FP8) quad8<0, 0>(acc, af8, w08, one); else quad<0, 0>(acc, af, w0);
             __builtin_amdgcn_s_barrier();
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                w1[ni][0] = *(const bf16x8*)(sb + 4096 + ni * 2048 + co0);
-                w1[ni][1] = *(const bf16x8*)(sb + 4096 + ni * 2048 + co1);
-            }
+            ld_w(w1, w18, sb + 4096);
             if (c1.valid) { if (afirst) stage_w(1, c1); else stage_a(0, c1); }
             __builtin_amdgcn_s_barrier();
-            quad<0, 1>(acc, af, w1);
+            if constexpr (FP8) quad8<0, 1>(acc, af8, w18, one); else quad<0, 1>(acc, af, w1);
             __builtin_amdgcn_s_barrier();
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                af[mi][0] = *(const bf16x8*)(sa + 8192 + mi * 2048 + co0);
-                af[mi][1] = *(const bf16x8*)(sa + 8192 + mi * 2048 + co1);
-            }
+            ld_a(sa + 8192);
             if (c1.valid && !afirst) stage_a(1, c1);
             __builtin_amdgcn_s_barrier();
-            quad<1, 1>(acc, af, w1);
+            if constexpr (FP8) quad8<1, 1>(acc, af8, w18, one); else quad<1, 1>(acc, af, w1);
             __builtin_amdgcn_s_barrier();
             const bool v1 = c1.valid, v2 = c2.valid;
             if (v2) stage_w0(c2);
@@ -211,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             };
             if (wr == 1) close_tile();
             __builtin_amdgcn_s_barrier();
-            quad<1, 0>(acc, af, w0);
+            if constexpr (FP8) quad8<1, 0>(acc, af8, w08, one); else quad<1, 0>(acc, af, w0);
             if (wr == 0) close_tile();
             __builtin_amdgcn_s_barrier();
             c1 = c2;
@@ -233,17 +267,27 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
         int row0, col0;
         tile_of(idx, row0, col0);
         char* const c_tile = (char*)p.C + ((size_t)(row0 + wr * 128) * p.ldc + col0 + wc * 64) * 2;
-        u32x4 bias[4];
+        u32x4 bias[4], wsc[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) bias[ni] = lds_read_b128(bias_r + ni * 64);
+        if constexpr (FP8) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) wsc[ni] = lds_read_b128(bias_r + (PSCALE - PBIAS) + ni * 64);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wsc[0]), "+v"(wsc[1]), "+v"(wsc[2]), "+v"(wsc[3]) :: "memory");
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]) :: "memory");
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {                 // 8 passes of 16 rows through the wave's private LDS area
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 f32x4 v = acc[mi][ni];
-                v[0] += __uint_as_float(bias[ni][0]); v[1] += __uint_as_float(bias[ni][1]);
-                v[2] += __uint_as_float(bias[ni][2]); v[3] += __uint_as_float(bias[ni][3]);
+                if constexpr (FP8) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaf(v[r], __uint_as_float(wsc[ni][r]), __uint_as_float(bias[ni][r]));
+                } else {
+                    v[0] += __uint_as_float(bias[ni][0]); v[1] += __uint_as_float(bias[ni][1]);
+                    v[2] += __uint_as_float(bias[ni][2]); v[3] += __uint_as_float(bias[ni][3]);
+                }
                 if constexpr (EPI == EPI_BIAS_QGELU_BF16) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
@@ -278,9 +322,9 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     if (wr == 0) __builtin_amdgcn_s_barrier();      // pairs with the extra barrier the wr == 1 half took at the start
 }
 
-template <int EPI>
+template <int EPI, bool FP8>
 static int launch256u(const GemmParams& p, hipStream_t stream) {
-    auto kern = gemm256u_bf16_nt_kernel<EPI>;
+    auto kern = gemm256u_bf16_nt_kernel<EPI, FP8>;
     static bool attr_done = false;
     static int num_cu = 0;
     if (!attr_done) {
@@ -303,10 +347,24 @@ static int launch256u(const GemmParams& p, hipStream_t stream) {
 // C must have ceil256(M) rows: rows in [M, ceil256(M)) are written (with values computed from A's pad rows).
 int launch_gemm256u(const GemmParams& p, int epi, hipStream_t stream) {
     switch (epi) {
-        case EPI_BIAS_BF16:       return launch256u<EPI_BIAS_BF16>(p, stream);
-        case EPI_BIAS_QGELU_BF16: return launch256u<EPI_BIAS_QGELU_BF16>(p, stream);
+        case EPI_BIAS_BF16:       return launch256u<EPI_BIAS_BF16, false>(p, stream);
+        case EPI_BIAS_QGELU_BF16: return launch256u<EPI_BIAS_QGELU_BF16, false>(p, stream);
     }
     KEMR_FAIL(KEMR_ERR_INVALID, "gemm256u: epilogue %d is not a bf16-store epilogue", epi);
+}
+
+// fp8 e4m3 operands: A [ceil256(M), lda] and W [N, ldw] in bytes, K % 128 == 0, K >= 256, N % 256 == 0; p.wscale[N] scales the
+// accumulators per output channel before the bias; C is bf16 as above.
+int launch_gemm256u_fp8(const GemmParams& p, int epi, hipStream_t stream) {
+    if (p.M <= 0) return KEMR_OK;
+    if (p.N % 256 != 0 || p.K % 128 != 0 || p.K < 256) KEMR_FAIL(KEMR_ERR_INVALID, "gemm fp8: need N %% 256 == 0, K %% 128 == 0, K >= 256 (got N=%d K=%d)", p.N, p.K);
+    if ((p.lda % 16) || (p.ldw % 16) || (p.ldc % 4)) KEMR_FAIL(KEMR_ERR_INVALID, "gemm fp8: leading dimensions must keep 16-byte alignment");
+    if (!p.wscale || !p.c_rows_padded) KEMR_FAIL(KEMR_ERR_INVALID, "gemm fp8: needs weight scales and a row-padded C");
+    switch (epi) {
+        case EPI_BIAS_BF16:       return launch256u<EPI_BIAS_BF16, true>(p, stream);
+        case EPI_BIAS_QGELU_BF16: return launch256u<EPI_BIAS_QGELU_BF16, true>(p, stream);
+    }
+    KEMR_FAIL(KEMR_ERR_INVALID, "gemm fp8: epilogue %d is not a bf16-store epilogue", epi);
 }
 
 }  // namespace kemr

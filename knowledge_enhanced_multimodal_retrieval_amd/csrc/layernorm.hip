@@ -27,6 +27,14 @@ __device__ __forceinline__ void store_row4(bf16_t* r, int i, float4 v) {
     ((uint2*)r)[i] = pk;
 }
 
+struct fp8_t { uint8_t v; };          // output tag: OCP e4m3 bytes (the A operand of the fp8 GEMMs), unit scale, saturating
+__device__ __forceinline__ void store_row4(fp8_t* r, int i, float4 v) {
+    const float lim = 448.f;
+    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v.x, -lim, lim), __builtin_amdgcn_fmed3f(v.y, -lim, lim), 0, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v.z, -lim, lim), __builtin_amdgcn_fmed3f(v.w, -lim, lim), pk, true);
+    ((int*)r)[i] = pk;
+}
+
 template <int NV, typename XT, typename OutT, int MODE>   // width = NV * 256
 __global__ __launch_bounds__(256) void layernorm_kernel(XT* x, const bf16_t* __restrict__ delta, const bf16_t* __restrict__ delta2,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -78,7 +86,13 @@ static int launch_nv(XT* x, const bf16_t* d1, const bf16_t* d2, int writeback, c
                      int out_dtype, hipStream_t s) {
     const int blocks = (rows + 3) / 4;
     ProfScope prof(PROF_LAYERNORM, s);
-    if (d1 && writeback)
+    if (d1 && writeback && out_dtype == KEMR_FP8)
+        hipLaunchKernelGGL((layernorm_kernel<NV, XT, fp8_t, 1>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (fp8_t*)y, rows, 1e-5f);
+    else if (d1 && out_dtype == KEMR_FP8)
+        hipLaunchKernelGGL((layernorm_kernel<NV, XT, fp8_t, 2>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (fp8_t*)y, rows, 1e-5f);
+    else if (out_dtype == KEMR_FP8)
+        hipLaunchKernelGGL((layernorm_kernel<NV, XT, fp8_t, 0>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (fp8_t*)y, rows, 1e-5f);
+    else if (d1 && writeback)
         hipLaunchKernelGGL((layernorm_kernel<NV, XT, bf16_t, 1>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (bf16_t*)y, rows, 1e-5f);
     else if (d1)
         hipLaunchKernelGGL((layernorm_kernel<NV, XT, bf16_t, 2>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (bf16_t*)y, rows, 1e-5f);
@@ -108,9 +122,9 @@ static int launch_xt(XT* x, const bf16_t* d1, const bf16_t* d2, int writeback, c
 int launch_layernorm(void* x, int x_dtype, const bf16_t* delta, const bf16_t* delta2, int writeback, const float* gamma,
                      const float* beta, void* y, int rows, int width, int out_dtype, hipStream_t stream) {
     if (rows <= 0) return KEMR_OK;
-    if (out_dtype != KEMR_BF16 && out_dtype != KEMR_F32) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: bad out dtype %d", out_dtype);
+    if (out_dtype != KEMR_BF16 && out_dtype != KEMR_F32 && out_dtype != KEMR_FP8) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: bad out dtype %d", out_dtype);
     if (x_dtype != KEMR_BF16 && x_dtype != KEMR_F32) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: bad row dtype %d", x_dtype);
-    if (delta && out_dtype != KEMR_BF16) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: the residual forms write bf16");
+    if (delta && out_dtype == KEMR_F32) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: the residual forms write bf16 or fp8");
     if (delta2 && !(delta && writeback)) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: a second delta needs the first one and writeback");
     if (x_dtype == KEMR_BF16) return launch_xt((bf16_t*)x, delta, delta2, writeback, gamma, beta, y, rows, width, out_dtype, stream);
     return launch_xt((float*)x, delta, delta2, writeback, gamma, beta, y, rows, width, out_dtype, stream);

@@ -32,7 +32,8 @@ class ClipEngine:
     """One packed CLIP model (both towers) in HBM."""
 
     def __init__(self, arch: ClipArch, device: torch.device | str = "cuda:0", precision: str = "bf16"):
-        """precision: "bf16" (fp32 residual stream) or "bf16-res16" (bf16 residual stream, see include/kemr.h)."""
+        """precision: "bf16" (fp32 residual stream), "bf16-res16" (bf16 residual stream), "fp8" (QKV GEMMs on fp8
+        operands, BASELINE config 5) or "fp8-mlp" (fc1 too); see kemr_precision in include/kemr.h."""
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
         self.precision = precision
@@ -313,6 +314,19 @@ def op_gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], m: i
     return c
 
 
+def op_gemm_fp8(a: torch.Tensor, w: torch.Tensor, wscale: torch.Tensor, bias: Optional[torch.Tensor], m: int,
+                epilogue: int) -> torch.Tensor:
+    """a, w: torch.float8_e4m3fn [ceil256(m), k] / [n, k]; returns bf16 [ceil256(m), n] = epi(a.w^T * wscale + bias)."""
+    L = _lib.lib()
+    n, k = w.shape
+    c = torch.zeros((a.shape[0], n), dtype=torch.bfloat16, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(L.kemr_op_gemm_fp8(C.c_void_p(a.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(wscale.data_ptr()),
+                                      _opt_ptr(bias), C.c_void_p(c.data_ptr()), m, n, k, epilogue,
+                                      C.c_void_p(_stream_ptr(a.device))), "op_gemm_fp8")
+    return c
+
+
 def op_layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_bf16: bool = True) -> torch.Tensor:
     L = _lib.lib()
     rows, width = x.shape
@@ -337,20 +351,22 @@ def op_layernorm_resid(x: torch.Tensor, delta: torch.Tensor, gamma: torch.Tensor
 
 
 def op_layernorm_rows(x: torch.Tensor, delta: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
-                      out_bf16: bool = True, delta2: Optional[torch.Tensor] = None, writeback: bool = True) -> torch.Tensor:
+                      out_bf16: bool = True, delta2: Optional[torch.Tensor] = None, writeback: bool = True,
+                      out_fp8: bool = False) -> torch.Tensor:
     """General form: x is fp32 or bf16 rows; returns LayerNorm(x [+ delta [+ delta2]]) (deltas bf16); with `writeback`
     the sum is stored back into x in x's dtype."""
     L = _lib.lib()
     rows, width = x.shape
     if x.dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError("op_layernorm_rows: x must be fp32 or bf16")
-    y = torch.empty((rows, width), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    ydt = torch.float8_e4m3fn if out_fp8 else (torch.bfloat16 if out_bf16 else torch.float32)
+    y = torch.empty((rows, width), dtype=ydt, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(L.kemr_op_layernorm_rows(C.c_void_p(x.data_ptr()), _lib.KEMR_BF16 if x.dtype == torch.bfloat16 else _lib.KEMR_F32,
                                             _opt_ptr(delta), _opt_ptr(delta2), 1 if writeback else 0,
                                             C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()),
                                             C.c_void_p(y.data_ptr()), rows, width,
-                                            _lib.KEMR_BF16 if out_bf16 else _lib.KEMR_F32,
+                                            _lib.KEMR_FP8 if out_fp8 else (_lib.KEMR_BF16 if out_bf16 else _lib.KEMR_F32),
                                             C.c_void_p(_stream_ptr(x.device))), "op_layernorm_rows")
     return y
 

@@ -89,3 +89,29 @@ def test_host_side_shape_checks():
     assert lib.kemr_profile_end(None, None, 0) == -2
     with pytest.raises(RuntimeError, match="libkemr"):
         _lib.check(-1, "x")
+
+
+def test_host_e4m3_conversion_matches_torch():
+    """Weights are quantised to OCP e4m3 on the host at finalize (KEMR_PREC_FP8): round to nearest even, subnormals,
+    saturation at +-448 -- against torch's float8_e4m3fn cast on every value it represents and on ties between them."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    lib = _lib.lib()
+    codes = torch.arange(256, dtype=torch.uint8)
+    vals = codes.view(torch.float8_e4m3fn).float()
+    finite = vals[~torch.isnan(vals)]
+    grid = torch.sort(finite).values
+    mids = (grid[1:] + grid[:-1]) / 2                       # exact ties
+    g = torch.Generator().manual_seed(0)
+    rnd = (torch.rand(20000, generator=g) * 2 - 1) * 440 * torch.rand(20000, generator=g) ** 6
+    x = torch.cat([finite, mids, rnd, torch.tensor([0.0, -0.0, 1e-9, 0.0009765, 0.00098, 447.9])]).contiguous()
+    out = np.empty(x.numel(), dtype=np.uint8)
+    assert lib.kemr_op_e4m3_host(C.c_void_p(x.data_ptr()), C.c_void_p(out.ctypes.data), x.numel()) == 0
+    ref = x.to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    same_value = torch.from_numpy(out).view(torch.float8_e4m3fn).float() == torch.from_numpy(ref).view(torch.float8_e4m3fn).float()
+    assert bool(same_value.all()), x[~same_value][:10]
+    big = torch.tensor([448.0, 449.0, 1e6, -1e6], dtype=torch.float32)      # saturating, unlike torch's cast
+    out2 = np.empty(4, dtype=np.uint8)
+    assert lib.kemr_op_e4m3_host(C.c_void_p(big.data_ptr()), C.c_void_p(out2.ctypes.data), 4) == 0
+    assert out2.tolist() == [0x7e, 0x7e, 0x7e, 0xfe]

@@ -134,6 +134,60 @@ def test_gemm_cross_tile_pipeline_k_tiles(device, k, variant):
         engine.set_gemm_variant(0)
 
 
+def _fp8(x):
+    return x.to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize("m,n,k", [(300, 768, 256), (1000, 1024, 1024), (256 * 70 + 19, 1024, 384), (63 * 257, 3072, 1024)])
+@pytest.mark.parametrize("epi", [_lib.EPI_BIAS_BF16, _lib.EPI_BIAS_QGELU_BF16])
+def test_gemm_fp8(device, m, n, k, epi):
+    """fp8 e4m3 operands through the block-scaled MFMA (K = 128 per instruction) against fp32 math on the same bytes."""
+    g = torch.Generator().manual_seed(m + n + k + epi)
+    m_alloc = (m + 255) // 256 * 256
+    a = _fp8(torch.randn(m_alloc, k, generator=g) * 1.5)
+    w = _fp8(torch.randn(n, k, generator=g) * 20)
+    wscale = (torch.rand(n, generator=g) + 0.5) * (k ** -0.5) / 20
+    bias = torch.randn(n, generator=g)
+    ref = (a.float()[:m] @ w.float().T) * wscale + bias
+    if epi == _lib.EPI_BIAS_QGELU_BF16:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    for _ in range(2):
+        out = engine.op_gemm_fp8(a.to(device), w.to(device), wscale.to(device), bias.to(device), m, epi)
+        torch.cuda.synchronize()
+        got = out.float().cpu()[:m]
+        assert float(((got - ref).abs() / (ref.abs() + 1.0)).max()) < 2e-2
+
+
+def test_gemm_fp8_identity_asymmetric(device):
+    """A = I against an asymmetric integer W: catches a wrong k order inside the 32-byte fragments."""
+    k = n = 512
+    a = _fp8(torch.eye(512, k))
+    w = ((torch.arange(n * k, dtype=torch.float32).reshape(n, k) * 7) % 17) - 8.0            # exact in e4m3
+    out = engine.op_gemm_fp8(a.to(device), _fp8(w).to(device), torch.ones(n, device=device), None, 512, _lib.EPI_BIAS_BF16)
+    torch.cuda.synchronize()
+    assert torch.equal(out.float().cpu(), w.T.contiguous())
+
+
+def test_layernorm_fp8_output(device):
+    width, rows = 1024, 301
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(rows, width, generator=g) * 2
+    d1 = (torch.randn(rows, width, generator=g) * 0.5).to(torch.bfloat16)
+    gamma, beta = 1 + 0.1 * torch.randn(width, generator=g), 0.1 * torch.randn(width, generator=g)
+    gamma[5] = 400.0                                                    # some outputs beyond +-448: must saturate, not NaN
+    gd, bd = gamma.to(device), beta.to(device)
+    for delta, wb in ((None, True), (d1, False), (d1, True)):
+        xd = x.clone().to(device)
+        y = engine.op_layernorm_rows(xd, None if delta is None else delta.to(device), gd, bd, writeback=wb, out_fp8=True)
+        torch.cuda.synchronize()
+        xs = x if delta is None else x + delta.float()
+        ref = torch.nn.functional.layer_norm(xs, (width,), gamma, beta, 1e-5).clamp(-448, 448)
+        got = y.float().cpu()
+        assert not torch.isnan(got).any()
+        # e4m3 has 3 mantissa bits: half an ulp is 1/16 relative for normals, 2^-10 absolute below 2^-6
+        assert float(((got - ref).abs() - ref.abs() / 16).max()) < 2e-3
+
+
 def test_gemm_rejects_bad_shapes(device):
     a = torch.zeros(256, 96, dtype=torch.bfloat16, device=device)
     w = torch.zeros(128, 96, dtype=torch.bfloat16, device=device)
