@@ -12,6 +12,8 @@ Inference only: ``encode_*`` run without autograd.  After changing parameters in
 """
 from __future__ import annotations
 
+import os
+
 from collections import OrderedDict
 from typing import Optional
 
@@ -119,7 +121,9 @@ class CLIP(nn.Module):
             raise RuntimeError("CLIP: the model sits on %s; the encoders run only on a GPU (model.to('cuda')); there is no "
                                "CPU fallback" % dev)
         if self._engine is None or self._engine.device != dev:
-            self._engine, self._dirty = ClipEngine(self.arch, dev), True
+            # encoder precision of the packed copy: "bf16" unless KEMR_PRECISION says otherwise (bf16-res16 | fp8 | fp8-mlp,
+            # kemr_precision in include/kemr.h) -- an environment switch so that the reference's scripts stay unchanged
+            self._engine, self._dirty = ClipEngine(self.arch, dev, precision=os.environ.get("KEMR_PRECISION", "bf16")), True
         if self._dirty:
             self._engine.load_state_dict({k: v for k, v in self.state_dict().items() if k != "logit_scale"})
             self._dirty = False
