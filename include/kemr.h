@@ -212,6 +212,15 @@ typedef enum kemr_epilogue {
 } kemr_epilogue;
 /* A bf16 [m_alloc, k] and C [m_alloc, n] with m_alloc = m rounded up to 256 rows (pad rows of A are read; pad rows of C
  * may be written by the bf16 epilogues), W bf16 [n, k], bias fp32 [n] */
+/* ---- image preprocessing on the GPU ------------------------------------------------
+ * Replaces the per-sample host transform the reference gets from clip.load (src/clip/datasets/clip_dataset.py:110-125):
+ * uint8 HWC RGB [height, width, 3] on the device -> Resize(n_px, bicubic, shorter side; Pillow's antialiased two-pass
+ * filter with 8-bit intermediates, bit-exact) -> CenterCrop(n_px) -> /255 -> (x - mean) / std -> fp32 CHW [3, n_px, n_px].
+ * The workspace holds the coefficient tables (uploaded by the call) and the horizontally filtered rows. */
+size_t kemr_preprocess_workspace_bytes(int height, int width, int n_px);
+int kemr_preprocess_u8(const unsigned char* img_dev, int height, int width, int n_px, float* out_dev,
+                       void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* tile variant used by every GEMM launch: 0 = automatic (default: 7 for the bf16 epilogues from 128 tiles up), 1 = 128x128x64
  * / 4 waves, 2 = 256x256x64 / 8 waves in lockstep, 3 = the same with staggered wave halves, 4 / 5 = persistent 256x256 with a
  * per-tile prologue (4 / 2 phases per K-tile), 6 = persistent, 4 waves x 128x128 (AGPR accumulators), 7 = persistent 8 waves,

@@ -60,6 +60,8 @@ SIGNATURES = {
     "kemr_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i64), _i]),
     "kemr_set_gemm_variant": (_i, [_i]),
     "kemr_op_gemm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "kemr_preprocess_workspace_bytes": (_sz, [_i, _i, _i]),
+    "kemr_preprocess_u8": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "kemr_op_gemm_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "kemr_op_e4m3_host": (_i, [_vp, _vp, C.c_longlong]),
     "kemr_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -1,0 +1,204 @@
+// CLIP image preprocessing on the GPU (the reference applies the callable it gets from
+// clip.load per sample on the host: /root/reference/src/clip/datasets/clip_dataset.py:110-125):
+//   uint8 HWC RGB -> Resize(n_px, bicubic, shorter side) -> CenterCrop(n_px) -> / 255 -> (x - mean) / std -> fp32 CHW.
+// The resize is Pillow's (Image.resize(..., BICUBIC), the dependency the reference's transform resolves to; libImaging
+// Resample.c as shipped in Pillow 12.2.0): an antialiased separable filter (support 2 * max(scale, 1), a = -0.5 cubic),
+// coefficients normalised in double and rounded to 22-bit fixed point, horizontal pass first, 8-bit clipped
+// intermediates.  Integer work, so it is reproduced bit for bit: the host computes the same coefficient tables (double
+// arithmetic in the same order) for the 2 x n_px output rows / columns that survive the crop, the kernels do the int32
+// accumulation.  Only the input rows the vertical pass needs are filtered horizontally.
+#include "common.h"
+
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#pragma STDC FP_CONTRACT OFF      // the coefficient arithmetic must round like Pillow's plain C doubles: no fused multiply-adds
+
+namespace kemr {
+
+namespace {
+
+constexpr int PRECISION_BITS = 32 - 8 - 2;
+
+double bicubic_filter(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+struct Axis {
+    bool resample = false;           // false: in_size == out_size, the pass is a copy
+    int ksize = 0, first = 0, count = 0;
+    int in_lo = 0, in_hi = 0;        // input index range touched by outputs [first, first + count)
+    std::vector<int32_t> kk;         // [count, ksize]
+    std::vector<int32_t> bounds;     // [count, 2]: xmin, number of taps
+};
+
+// Resample.c precompute_coeffs + normalize_coeffs_8bpc, for the output indices [first, first + count) only
+void precompute(int in_size, int out_size, int first, int count, Axis& ax) {
+    ax.first = first; ax.count = count;
+    ax.resample = in_size != out_size;
+    if (!ax.resample) { ax.in_lo = first; ax.in_hi = first + count; return; }
+    const double scale = (double)in_size / out_size;
+    double filterscale = scale;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 2.0 * filterscale;
+    ax.ksize = (int)ceil(support) * 2 + 1;
+    ax.kk.assign((size_t)count * ax.ksize, 0);
+    ax.bounds.assign((size_t)count * 2, 0);
+    ax.in_lo = in_size; ax.in_hi = 0;
+    std::vector<double> k(ax.ksize);
+    for (int i = 0; i < count; ++i) {
+        const int xx = first + i;
+        const double center = 0.0 + (xx + 0.5) * scale;
+        double ww = 0.0;
+        const double ss = 1.0 / filterscale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < xmax; ++x) {
+            const double w = bicubic_filter((x + xmin - center + 0.5) * ss);
+            k[x] = w;
+            ww += w;
+        }
+        for (int x = 0; x < xmax; ++x)
+            if (ww != 0.0) k[x] /= ww;
+        for (int x = 0; x < xmax; ++x)
+            ax.kk[(size_t)i * ax.ksize + x] = k[x] < 0 ? (int32_t)(-0.5 + k[x] * (1 << PRECISION_BITS)) : (int32_t)(0.5 + k[x] * (1 << PRECISION_BITS));
+        ax.bounds[2 * i] = xmin; ax.bounds[2 * i + 1] = xmax;
+        if (xmin < ax.in_lo) ax.in_lo = xmin;
+        if (xmin + xmax > ax.in_hi) ax.in_hi = xmin + xmax;
+    }
+}
+
+struct Plan {
+    int nw = 0, nh = 0, left = 0, top = 0;
+    Axis hx, vy;
+    std::vector<int32_t> table;      // hx.kk | hx.bounds | vy.kk | vy.bounds, as uploaded
+    size_t off_hb = 0, off_vk = 0, off_vb = 0, temp_off = 0, bytes = 0;
+};
+
+const Plan& plan_for(int height, int width, int n) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int>, Plan> cache;      // entries are never modified once inserted
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_tuple(height, width, n);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    Plan p;
+    // Resize(n): shorter side -> n, the other side int(n * long / short) (torchvision / clip _transform)
+    if (width <= height) { p.nw = n; p.nh = (int)((double)n * height / width); }
+    else { p.nw = (int)((double)n * width / height); p.nh = n; }
+    // CenterCrop(n): int(round((size - n) / 2.0)) with Python's round-half-to-even
+    p.left = (int)nearbyint((p.nw - n) / 2.0);
+    p.top = (int)nearbyint((p.nh - n) / 2.0);
+    precompute(width, p.nw, p.left, n, p.hx);
+    precompute(height, p.nh, p.top, n, p.vy);
+    p.table = p.hx.kk;
+    p.off_hb = p.table.size(); p.table.insert(p.table.end(), p.hx.bounds.begin(), p.hx.bounds.end());
+    p.off_vk = p.table.size(); p.table.insert(p.table.end(), p.vy.kk.begin(), p.vy.kk.end());
+    p.off_vb = p.table.size(); p.table.insert(p.table.end(), p.vy.bounds.begin(), p.vy.bounds.end());
+    p.temp_off = (size_t)round_up((int64_t)p.table.size() * 4, 256);
+    p.bytes = p.temp_off + (size_t)round_up((int64_t)(p.vy.in_hi - p.vy.in_lo) * n * 3, 256);
+    return cache.emplace(key, std::move(p)).first->second;
+}
+
+__device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+// horizontal pass over the input rows [row_lo, row_lo + rows): temp[r][xx][c], xx = cropped output column
+__global__ __launch_bounds__(256) void preprocess_h_kernel(const uint8_t* __restrict__ img, int width, int row_lo, int rows, int n,
+                                                           const int32_t* __restrict__ kk, const int32_t* __restrict__ bounds,
+                                                           int ksize, int resample, int left, uint8_t* __restrict__ temp) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= rows * n) return;
+    const int r = gid / n, xx = gid - r * n;
+    const uint8_t* src = img + ((size_t)(row_lo + r) * width) * 3;
+    uint8_t* dst = temp + ((size_t)r * n + xx) * 3;
+    if (!resample) {
+        const uint8_t* s = src + (size_t)(left + xx) * 3;
+        dst[0] = s[0]; dst[1] = s[1]; dst[2] = s[2];
+        return;
+    }
+    const int xmin = bounds[2 * xx], cnt = bounds[2 * xx + 1];
+    const int32_t* k = kk + (size_t)xx * ksize;
+    int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+    for (int x = 0; x < cnt; ++x) {
+        const uint8_t* s = src + (size_t)(xmin + x) * 3;
+        const int c = k[x];
+        s0 += s[0] * c; s1 += s[1] * c; s2 += s[2] * c;
+    }
+    dst[0] = (uint8_t)clip8(s0 >> PRECISION_BITS); dst[1] = (uint8_t)clip8(s1 >> PRECISION_BITS); dst[2] = (uint8_t)clip8(s2 >> PRECISION_BITS);
+}
+
+// vertical pass + ToTensor + Normalize: out[c][yy][xx] = (v / 255 - mean[c]) / std[c], fp32 operations in torch's order
+__global__ __launch_bounds__(256) void preprocess_v_kernel(const uint8_t* __restrict__ temp, int row_lo, int n,
+                                                           const int32_t* __restrict__ kk, const int32_t* __restrict__ bounds,
+                                                           int ksize, int resample, int top, float m0, float m1, float m2,
+                                                           float d0, float d1, float d2, float* __restrict__ out) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n * n) return;
+    const int yy = gid / n, xx = gid - yy * n;
+    int v0, v1, v2;
+    if (!resample) {
+        const uint8_t* s = temp + ((size_t)(top + yy - row_lo) * n + xx) * 3;
+        v0 = s[0]; v1 = s[1]; v2 = s[2];
+    } else {
+        const int ymin = bounds[2 * yy], cnt = bounds[2 * yy + 1];
+        const int32_t* k = kk + (size_t)yy * ksize;
+        int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+        for (int y = 0; y < cnt; ++y) {
+            const uint8_t* s = temp + ((size_t)(ymin + y - row_lo) * n + xx) * 3;
+            const int c = k[y];
+            s0 += s[0] * c; s1 += s[1] * c; s2 += s[2] * c;
+        }
+        v0 = clip8(s0 >> PRECISION_BITS); v1 = clip8(s1 >> PRECISION_BITS); v2 = clip8(s2 >> PRECISION_BITS);
+    }
+    const size_t plane = (size_t)n * n;
+    out[gid] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)v0, 255.0f), m0), d0);
+    out[plane + gid] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)v1, 255.0f), m1), d1);
+    out[2 * plane + gid] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)v2, 255.0f), m2), d2);
+}
+
+}  // namespace
+
+}  // namespace kemr
+
+using namespace kemr;
+
+extern "C" size_t kemr_preprocess_workspace_bytes(int height, int width, int n_px) {
+    if (height <= 0 || width <= 0 || n_px <= 0 || height > 32768 || width > 32768 || n_px > 1024) return 0;
+    return plan_for(height, width, n_px).bytes;
+}
+
+extern "C" int kemr_preprocess_u8(const unsigned char* img_dev, int height, int width, int n_px, float* out_dev,
+                                  void* workspace_dev, size_t workspace_bytes, void* stream) {
+    if (!img_dev || !out_dev) KEMR_FAIL(KEMR_ERR_INVALID, "preprocess: null argument");
+    if (height <= 0 || width <= 0 || n_px <= 0 || height > 32768 || width > 32768 || n_px > 1024)
+        KEMR_FAIL(KEMR_ERR_INVALID, "preprocess: bad sizes %d x %d -> %d", height, width, n_px);
+    const Plan& p = plan_for(height, width, n_px);
+    if (!workspace_dev || workspace_bytes < p.bytes) KEMR_FAIL(KEMR_ERR_WORKSPACE, "preprocess: workspace too small: %zu < %zu bytes", workspace_bytes, p.bytes);
+    if ((uintptr_t)workspace_dev % 256) KEMR_FAIL(KEMR_ERR_WORKSPACE, "preprocess: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int n = n_px;
+    int32_t* tab = (int32_t*)workspace_dev;
+    uint8_t* temp = (uint8_t*)workspace_dev + p.temp_off;
+    if (!p.table.empty()) KEMR_CHECK_HIP(hipMemcpyAsync(tab, p.table.data(), p.table.size() * 4, hipMemcpyHostToDevice, s));
+    const int row_lo = p.vy.in_lo, rows = p.vy.in_hi - p.vy.in_lo;
+    ProfScope prof(PROF_OTHER, s);
+    hipLaunchKernelGGL(preprocess_h_kernel, dim3((unsigned)(((size_t)rows * n + 255) / 256)), dim3(256), 0, s, img_dev, width, row_lo, rows, n,
+                       tab, tab + p.off_hb, p.hx.ksize, p.hx.resample ? 1 : 0, p.left, temp);
+    KEMR_CHECK_LAUNCH("preprocess_h_kernel");
+    // CLIP's normalisation constants
+    hipLaunchKernelGGL(preprocess_v_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, s, temp, row_lo, n, tab + p.off_vk,
+                       tab + p.off_vb, p.vy.ksize, p.vy.resample ? 1 : 0, p.top, 0.48145466f, 0.4578275f, 0.40821073f, 0.26862954f,
+                       0.26130258f, 0.27577711f, out_dev);
+    KEMR_CHECK_LAUNCH("preprocess_v_kernel");
+    return KEMR_OK;
+}

@@ -34,3 +34,41 @@ class ClipPreprocess:
 
     def __repr__(self):
         return f"ClipPreprocess(n_px={self.n_px})"
+
+
+class ClipPreprocessGPU:
+    """The same transform as :class:`ClipPreprocess`, computed by the HIP kernels (csrc/preprocess.hip) and bit-identical
+    to it: takes a PIL image (RGB is enforced before the resize here; identical for RGB inputs) or a uint8 ``[H, W, 3]``
+    tensor on any device, returns float32 ``[3, n_px, n_px]`` on ``device``.  No CPU fallback."""
+
+    def __init__(self, n_px: int = 224, device="cuda:0"):
+        self.n_px = n_px
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("ClipPreprocessGPU needs a GPU device")
+        self._ws = None
+
+    def __call__(self, image) -> torch.Tensor:
+        import ctypes as C
+        from . import _lib, engine
+        if not torch.is_tensor(image):
+            image = torch.from_numpy(np.asarray(image.convert("RGB"), dtype=np.uint8).copy())
+        if image.dtype != torch.uint8 or image.dim() != 3 or image.shape[2] != 3:
+            raise RuntimeError(f"ClipPreprocessGPU expects uint8 [H, W, 3], got {image.dtype} {tuple(image.shape)}")
+        img = image.to(self.device).contiguous()
+        h, w = int(img.shape[0]), int(img.shape[1])
+        L = _lib.lib()
+        need = int(L.kemr_preprocess_workspace_bytes(h, w, self.n_px))
+        if need == 0:
+            raise RuntimeError(f"ClipPreprocessGPU: unsupported size {h} x {w} -> {self.n_px}")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out = torch.empty((3, self.n_px, self.n_px), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(L.kemr_preprocess_u8(C.c_void_p(img.data_ptr()), h, w, self.n_px, C.c_void_p(out.data_ptr()),
+                                            C.c_void_p(self._ws.data_ptr()), self._ws.numel(),
+                                            C.c_void_p(engine._stream_ptr(self.device))), "preprocess_u8")
+        return out
+
+    def __repr__(self):
+        return f"ClipPreprocessGPU(n_px={self.n_px})"

@@ -1,0 +1,62 @@
+"""Image transform: the oracle restatement against Pillow itself (CPU, bit-exact) and the HIP kernels
+against the host transform the drop-in modules use (GPU, bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+from knowledge_enhanced_multimodal_retrieval_amd.preprocess import ClipPreprocess, ClipPreprocessGPU
+from oracle import preprocess_ref
+
+SIZES = [(300, 400), (224, 500), (999, 224), (1080, 1920), (231, 229), (100, 80), (640, 480), (225, 224), (224, 224),
+         (37, 1000), (2000, 1500)]
+
+
+def _image(h, w, seed):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    if seed % 2:                                   # smooth content as well as noise
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), ((xx + yy) % 256)], -1).astype(np.uint8)
+    return base
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_oracle_resize_equals_pillow(h, w):
+    from PIL import Image
+    arr = _image(h, w, h + w)
+    nw, nh = preprocess_ref.resized_size(h, w, 224)
+    pil = np.asarray(Image.fromarray(arr).resize((nw, nh), Image.BICUBIC))
+    assert np.array_equal(preprocess_ref.resize_bicubic_u8(arr, nw, nh), pil)
+
+
+@pytest.mark.parametrize("h,w", SIZES[:6])
+def test_oracle_transform_equals_host_transform(h, w):
+    from PIL import Image
+    arr = _image(h, w, h * 3 + w)
+    want = ClipPreprocess(224)(Image.fromarray(arr)).numpy()
+    assert np.array_equal(preprocess_ref.clip_preprocess(arr, 224), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w", SIZES)
+def test_gpu_transform_is_bit_exact(device, h, w):
+    from PIL import Image
+    arr = _image(h, w, h + 2 * w)
+    want = ClipPreprocess(224)(Image.fromarray(arr))
+    pre = ClipPreprocessGPU(224, device)
+    got = pre(torch.from_numpy(arr))
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), want)
+    assert torch.equal(pre(Image.fromarray(arr)).cpu(), want)          # PIL input, workspace reused
+
+
+@pytest.mark.gpu
+def test_gpu_transform_other_resolution_and_errors(device):
+    from PIL import Image
+    arr = _image(500, 333, 7)
+    want = ClipPreprocess(336)(Image.fromarray(arr))
+    assert torch.equal(ClipPreprocessGPU(336, device)(torch.from_numpy(arr)).cpu(), want)
+    with pytest.raises(RuntimeError, match="uint8"):
+        ClipPreprocessGPU(224, device)(torch.zeros(10, 10, 3))
+    with pytest.raises(RuntimeError, match="GPU"):
+        ClipPreprocessGPU(224, "cpu")
