@@ -179,6 +179,8 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     const bool can256 = p.N % 256 == 0 && p.K >= 128;
     const long tiles256 = (long)((p.M + 255) / 256) * (p.N / 256);
     const bool bf16_epi = epi == EPI_BIAS_BF16 || epi == EPI_BIAS_QGELU_BF16;
+    // a handful of rows (one or a few online queries): 6-24 tiles would leave the chip idle; split K inside the workgroup
+    if (bf16_epi && p.c_rows_padded && (g_gemm_variant == 8 || (g_gemm_variant == 0 && p.M <= 512))) return launch_gemm_skinny(p, epi, stream);
     if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 5) return launch_gemm256q(p, epi, stream);
     if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 6) return launch_gemm256w(p, epi, stream);
     if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 4) return launch_gemm256p(p, epi, stream);

@@ -134,6 +134,18 @@ def test_gemm_cross_tile_pipeline_k_tiles(device, k, variant):
         engine.set_gemm_variant(0)
 
 
+@pytest.mark.parametrize("m,n,k", [(77, 2304, 768), (77, 768, 3072), (1, 768, 768), (257, 1024, 1024), (300, 3072, 768), (512, 256, 64), (129, 512, 192)])
+@pytest.mark.parametrize("epi", [_lib.EPI_BIAS_BF16, _lib.EPI_BIAS_QGELU_BF16])
+def test_gemm_skinny(device, m, n, k, epi):
+    """Online-query shapes (M = 77 for one text, 257 for one image): split-K kernel, forced and as the automatic choice."""
+    for variant in (8, 0):
+        engine.set_gemm_variant(variant)
+        try:
+            _gemm_epilogue_case(device, m, n, k, epi)
+        finally:
+            engine.set_gemm_variant(0)
+
+
 def _fp8(x):
     return x.to(torch.float8_e4m3fn)
 
