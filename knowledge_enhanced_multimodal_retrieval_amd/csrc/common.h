@@ -105,7 +105,7 @@ struct GemmParams {
     int M, N, K;         // M = valid rows (stores are guarded), N % 128 == 0, K % 64 == 0
     int lda, ldw, ldc;
     int patches;         // EPI_PATCH_F32: patches per image (row remap m -> m + m / patches + 1)
-    int dbg;             // timing experiments only (tools/): bit 0 = skip the epilogue stores; gemm256u: 4 = plain (not nt) stores, 32 = half the stores
+    int dbg;             // timing experiments only (tools/): 1 = skip the epilogue stores, 2 = drain vmcnt at every wait (gemm256p/q); gemm256u: 4 = plain instead of nt stores, 32 = half the stores
     int c_rows_padded;   // C has ceil256(M) writable rows (lets the persistent kernel store without row masks)
 };
 extern int g_gemm_dbg;

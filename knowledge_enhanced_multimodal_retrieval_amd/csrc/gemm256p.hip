@@ -142,11 +142,6 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_nt_kernel(const GemmPara
     const unsigned epi_r1 = epi_r0 + 1024;                                           // (er + 8) & 7 == er
 
     if (!p.bias && tid < 128) *(float4*)(smem + PBIAS + tid * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.dbg & 4) {      // experiment: start the workgroups in 4 phase groups a quarter tile apart (de-synchronise store bursts)
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 3) * nt * 800ull;
-        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
     int row0, col0;
     tile_of(blockIdx.x, row0, col0);
     set_src(row0, col0);
@@ -218,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_bf16_nt_kernel(const GemmPara
             if (more2) stage_w(0, t + 2);
             auto close_tile = [&]() {
                 if (p.dbg & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if ((t == 0 || ((p.dbg & 8) && t < 6)) && had_stores) {   // dbg 8: TIMING ONLY (wrong results): stores may fly 6 K-tiles
+                if (t == 0 && had_stores) {
                     if (more2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 } else {

@@ -106,7 +106,10 @@ __global__ __launch_bounds__(256) void sim_kernel(const SimParams p) {
     constexpr int TILE_BYTES = ST * SBK * 2;             // 16 KiB per operand tile
     constexpr int STAGE_BYTES = 2 * TILE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sS = (float*)(smem + 2 * STAGE_BYTES);        // [128][132] fp32 score tile (also the list exchange area)
+    // [128][132] fp32 score tile (also the list exchange area).  It ALIASES the two operand stages: they are dead between
+    // the last K-tile's barrier and the next tile's first stage, which is behind the barrier that ends the scan.  66 KiB
+    // of LDS instead of 130 lets two workgroups share a CU, so one scans while the other is in its MFMA loop.
+    float* sS = (float*)smem;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -233,11 +236,10 @@ __global__ __launch_bounds__(256) void sim_kernel(const SimParams p) {
                 }
             }
         }
-        // no barrier needed here: the next write to sS happens after the barriers of the next K loop
+        __syncthreads();          // the scan is done with sS before the next tile's operands are staged over it
     }
 
     if constexpr (!DENSE) {
-        __syncthreads();
         float* xs = sS;                                   // [128][2][KMAX] scores
         int* xi = (int*)(sS + ST * 2 * KMAX);             // [128][2][KMAX] ids
 #pragma unroll
@@ -451,7 +453,8 @@ extern "C" size_t kemr_sim_workspace_bytes(int nq, int ng, int k) {
 
 template <int KMAX, bool DENSE>
 static int launch_sim(const SimParams& p, hipStream_t stream) {
-    constexpr int smem = 2 * 2 * ST * SBK * 2 + ST * SLD * 4;
+    constexpr int stages = 2 * 2 * ST * SBK * 2, tile = ST * SLD * 4;
+    constexpr int smem = stages > tile ? stages : tile;      // the score tile aliases the stages
     auto kern = sim_kernel<KMAX, DENSE>;
     KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     const int q_tiles = (p.nq + ST - 1) / ST;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Timing experiment: persistent GEMM with debug flags (1 no stores, 4 staggered start, 16 non-temporal stores) on the
-encoder shapes, next to torch's F.linear (hipBLASLt) as an outside yardstick."""
+"""Timing experiment: GEMM variants (low byte) with debug flags (second byte: 1 = no C stores, gemm256u: 4 = plain instead of
+non-temporal stores, 32 = half the stores) on the encoder shapes, 10-launch bursts, next to torch's F.linear (hipBLASLt) as
+an outside yardstick.  For sustained-clock numbers use bench_gemm_sustained.py."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
