@@ -1,8 +1,8 @@
 #!/bin/bash
-# Evidence run for profiles/: un-profiled bench line, rocprofv3 kernel stats of the same command, HBM traffic PMC passes.
-# usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>_*
+# Evidence run for profiles/: un-profiled bench line, rocprofv3 kernel stats of the same command, optional PMC passes.
+# usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag> [pmc]      -> gpurun_out/<tag>_*
 set -e
-TAG=${1:-r01_v5}
+TAG=${1:-r01_v6}
 R=$(pwd)
 OUT=$R/gpurun_out
 mkdir -p $OUT
@@ -11,8 +11,10 @@ echo "[profile] bench"; python3 $R/bench.py > $OUT/${TAG}_bench.log 2>&1; tail -
 echo "[profile] kernel stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.log 2>&1
 tail -n 1 $OUT/${TAG}_bench_under_rocprof.log > $OUT/${TAG}_bench_under_rocprof.json
-echo "[profile] pmc FETCH_SIZE"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-sim > $OUT/${TAG}_pmc_fetch.log 2>&1
-echo "[profile] pmc WRITE_SIZE"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-sim > $OUT/${TAG}_pmc_write.log 2>&1
+if [ "$2" = "pmc" ]; then
+  echo "[profile] pmc FETCH_SIZE"
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-sim > $OUT/${TAG}_pmc_fetch.log 2>&1
+  echo "[profile] pmc WRITE_SIZE"
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-sim > $OUT/${TAG}_pmc_write.log 2>&1
+fi
 echo "[profile] done"
