@@ -83,7 +83,7 @@ __device__ __forceinline__ void quad8(f32x4 (&acc)[8][4], const fp8x32 (&af)[4],
 
 }  // namespace
 
-template <int EPI, bool FP8>
+template <int EPI, bool FP8, bool AFIRST>
 __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmParams p) {
     constexpr int ES = FP8 ? 1 : 2;          // operand element size
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -109,7 +109,8 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     // from HBM, 4 tiles per A panel): the A halves first, a full K-tile ahead of their use, then W1 (measured, sustained:
     // 470 -> 443 us at K = 4096).  Short K (A panels shared by 12-16 column tiles, mostly L2 hits): W1, A0, A1 spread over
     // the first three intervals is 1 % faster.
-    const bool afirst = nt >= 32;
+    // (a template parameter: a run-time branch at the three staging sites of this loop costs several per cent)
+    constexpr bool afirst = AFIRST;
 
     // staging addresses = wave-uniform K-tile base (SGPRs) + a per-lane 32-bit byte offset that never changes
     const int srow = lane >> 3, schunk = lane & 7;
@@ -322,9 +323,9 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     if (wr == 0) __builtin_amdgcn_s_barrier();      // pairs with the extra barrier the wr == 1 half took at the start
 }
 
-template <int EPI, bool FP8>
-static int launch256u(const GemmParams& p, hipStream_t stream) {
-    auto kern = gemm256u_bf16_nt_kernel<EPI, FP8>;
+template <int EPI, bool FP8, bool AFIRST>
+static int launch256u_a(const GemmParams& p, hipStream_t stream) {
+    auto kern = gemm256u_bf16_nt_kernel<EPI, FP8, AFIRST>;
     static bool attr_done = false;
     static int num_cu = 0;
     if (!attr_done) {
@@ -342,6 +343,12 @@ static int launch256u(const GemmParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), PSMEM, stream, q);
     KEMR_CHECK_LAUNCH("gemm256u_bf16_nt_kernel");
     return KEMR_OK;
+}
+
+template <int EPI, bool FP8>
+static int launch256u(const GemmParams& p, hipStream_t stream) {
+    const int nt = FP8 ? p.K >> 7 : p.K >> 6;
+    return nt >= 32 ? launch256u_a<EPI, FP8, true>(p, stream) : launch256u_a<EPI, FP8, false>(p, stream);
 }
 
 // C must have ceil256(M) rows: rows in [M, ceil256(M)) are written (with values computed from A's pad rows).
