@@ -83,7 +83,7 @@ __device__ __forceinline__ void quad8(f32x4 (&acc)[8][4], const fp8x32 (&af)[4],
 
 }  // namespace
 
-template <int EPI, bool FP8, bool AFIRST>
+template <int EPI, bool FP8, bool AFIRST, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmParams p) {
     constexpr int ES = FP8 ? 1 : 2;          // operand element size
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -308,10 +308,11 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             // all non-temporal 14 065; every one of the four contributes, the LayerNorm reading the deltas included.
             // Inline asm because __builtin_nontemporal_store did not produce this encoding; 2 stores per lane and pass,
             // the vmcnt bookkeeping in the header counts them.
-            if (!(p.dbg & 1) && !((p.dbg & 32) && mi >= 4)) {          // dbg 1 / 32: TIMING ONLY, all / half the stores dropped
+            // the timing-experiment flags exist only in the DBG instantiation (tools/: any non-zero flag selects it)
+            if (!DBG || (!(p.dbg & 1) && !((p.dbg & 32) && mi >= 4))) {          // dbg 1 / 32: TIMING ONLY, all / half the stores dropped
                 char* q0 = c_tile + (size_t)(mi * 16) * p.ldc * 2 + c_lane;
                 char* q1 = c_tile + (size_t)(mi * 16 + 8) * p.ldc * 2 + c_lane;
-                if (p.dbg & 4)
+                if (DBG && (p.dbg & 4))
                     asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %2, %3, off\n\ts_nop 1"
                                  :: "v"(q0), "v"(d0), "v"(q1), "v"(d1) : "memory");        // dbg 4: plain stores, for A/B
                 else
@@ -323,9 +324,9 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     if (wr == 0) __builtin_amdgcn_s_barrier();      // pairs with the extra barrier the wr == 1 half took at the start
 }
 
-template <int EPI, bool FP8, bool AFIRST>
+template <int EPI, bool FP8, bool AFIRST, bool DBG>
 static int launch256u_a(const GemmParams& p, hipStream_t stream) {
-    auto kern = gemm256u_bf16_nt_kernel<EPI, FP8, AFIRST>;
+    auto kern = gemm256u_bf16_nt_kernel<EPI, FP8, AFIRST, DBG>;
     static bool attr_done = false;
     static int num_cu = 0;
     if (!attr_done) {
@@ -348,7 +349,8 @@ static int launch256u_a(const GemmParams& p, hipStream_t stream) {
 template <int EPI, bool FP8>
 static int launch256u(const GemmParams& p, hipStream_t stream) {
     const int nt = FP8 ? p.K >> 7 : p.K >> 6;
-    return nt >= 32 ? launch256u_a<EPI, FP8, true>(p, stream) : launch256u_a<EPI, FP8, false>(p, stream);
+    if (g_gemm_dbg && !FP8) return nt >= 32 ? launch256u_a<EPI, false, true, true>(p, stream) : launch256u_a<EPI, false, false, true>(p, stream);
+    return nt >= 32 ? launch256u_a<EPI, FP8, true, false>(p, stream) : launch256u_a<EPI, FP8, false, false>(p, stream);
 }
 
 // C must have ceil256(M) rows: rows in [M, ceil256(M)) are written (with values computed from A's pad rows).
