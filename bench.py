@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--model", default="ViT-L/14")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16-res16", "fp8", "fp8-mlp"],
                     help="bf16 operands with an fp32 (default) or bf16 residual stream")
+    ap.add_argument("--image-slice", type=int, default=0, help="experiment: images per encoder launch (default: the engine's 255)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="A/B only: force a GEMM tile variant (0 = the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sim", action="store_true")
@@ -137,6 +138,8 @@ def main():
     arch = ARCHS[args.model]
     B = args.batch
     eng = engine.ClipEngine(arch, dev, precision=args.precision)
+    if args.image_slice:
+        engine.MAX_IMAGE_BATCH = args.image_slice
     if args.gemm_variant:
         engine.set_gemm_variant(args.gemm_variant)
     eng.load_state_dict(random_weights(arch, seed=0))
