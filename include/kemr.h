@@ -225,7 +225,7 @@ int kemr_preprocess_u8(const unsigned char* img_dev, int height, int width, int 
  * / 4 waves, 2 = 256x256x64 / 8 waves in lockstep, 3 = the same with staggered wave halves, 4 / 5 = persistent 256x256 with a
  * per-tile prologue (4 / 2 phases per K-tile), 6 = persistent, 4 waves x 128x128 (AGPR accumulators), 7 = persistent 8 waves,
  * one K-tile pipeline across tiles, non-temporal C stores (2-7 need N % 256 == 0; 4-7 the bf16 epilogues), 8 = skinny-M split-K
- * (default up to 512 rows, bf16 epilogues); A/B and tests */
+ * (default up to 512 rows, bf16 epilogues), 9 = persistent, 4 waves x 128x128, register-staged operands; A/B and tests */
 int kemr_set_gemm_variant(int variant);
 int kemr_op_gemm(const void* a_dev, const void* w_dev, const float* bias_dev, void* c_dev,
                  int m, int n, int k, int epilogue, void* stream);

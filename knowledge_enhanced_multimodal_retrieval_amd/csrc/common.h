@@ -115,6 +115,7 @@ int launch_gemm256p(const GemmParams& p, int epi, hipStream_t stream);  // gemm2
 int launch_gemm256q(const GemmParams& p, int epi, hipStream_t stream);  // gemm256q.hip: persistent, 2 long phases per K-tile
 int launch_gemm256u(const GemmParams& p, int epi, hipStream_t stream);  // gemm256u.hip: gemm256p's K loop, one K-tile pipeline across tiles
 int launch_gemm256u_fp8(const GemmParams& p, int epi, hipStream_t stream);  // gemm256u.hip: fp8 e4m3 operands (A, W in bytes), bf16 C
+int launch_gemm256r(const GemmParams& p, int epi, hipStream_t stream);  // gemm256r.hip: persistent, 4 waves x 128x128, register-staged operands
 int launch_gemm_skinny(const GemmParams& p, int epi, hipStream_t stream);   // gemm_skinny.hip: M <= 512 rows (online queries), split-K over 8 waves
 int launch_gemm256w(const GemmParams& p, int epi, hipStream_t stream);  // gemm256w.hip: persistent, 4 waves x 128x128 (AGPR accumulators)
 extern int g_gemm_variant;   // 0 auto, 1 = 128x128 (gemm.hip), 2 / 3 = 256x256 lockstep / staggered, 4 = persistent 256x256 (bf16 epilogues)

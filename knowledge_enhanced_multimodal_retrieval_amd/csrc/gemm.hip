@@ -183,6 +183,7 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     if (bf16_epi && p.c_rows_padded && (g_gemm_variant == 8 || (g_gemm_variant == 0 && p.M <= 512))) return launch_gemm_skinny(p, epi, stream);
     if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 5) return launch_gemm256q(p, epi, stream);
     if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 6) return launch_gemm256w(p, epi, stream);
+    if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 9) return launch_gemm256r(p, epi, stream);
     if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 4) return launch_gemm256p(p, epi, stream);
     if (can256 && bf16_epi && p.c_rows_padded && (g_gemm_variant == 7 || (g_gemm_variant == 0 && tiles256 >= 128)))
         return launch_gemm256u(p, epi, stream);

@@ -7,9 +7,9 @@ import torch
 from knowledge_enhanced_multimodal_retrieval_amd import engine
 dev = torch.device("cuda:0")
 B = 255
-shapes = [("v.qkv", B * 257, 3072, 1024, 0), ("v.out", B * 257, 1024, 1024, 0), ("v.fc1", B * 257, 4096, 1024, 1), ("v.fc2", B * 257, 1024, 4096, 0)]
+shapes = [("v.qkv", B * 257, 3072, 1024, 0), ("v.out", B * 257, 1024, 1024, 0), ("v.fc1", B * 257, 4096, 1024, 1), ("v.fc2", B * 257, 1024, 4096, 0), ("sq4096", 4096, 4096, 4096, 0)]
 g = torch.Generator(device=dev).manual_seed(0)
-cands = [("v4", 4), ("v7", 7), ("torch", "torch")]
+cands = [("v7", 7), ("v9_regstaged", 9), ("torch", "torch")]
 for name, m, n, k, epi in shapes:
     ma = (m + 255) // 256 * 256
     a = torch.randn(ma, k, generator=g, device=dev).to(torch.bfloat16)
