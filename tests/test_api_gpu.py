@@ -60,6 +60,27 @@ def test_config0_vit_b32_zeroshot_256(device, tmp_path):
     assert sum(abs(res["metrics"][k] - exact[k]) > 1e-9 for k in exact) <= 4
 
 
+@pytest.mark.parametrize("precision", ["bf16-res16", "fp8", "fp8-mlp"])
+def test_precision_switch_reaches_the_drop_in_modules(device, tmp_path, monkeypatch, precision):
+    """KEMR_PRECISION selects the encoder precision behind the unchanged CLI: the evaluator runs and its
+    embeddings differ from the bf16 run by what that precision costs, no more."""
+    import clip
+    from knowledge_enhanced_multimodal_retrieval_amd import datasets, evaluators
+    ds = datasets.SyntheticRetrievalDataset(64, 224, seed=7)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        monkeypatch.delenv("KEMR_PRECISION", raising=False)
+        base, _ = clip.load("ViT-B/32", device="cuda")
+        ref_img, ref_qry, _, _ = evaluators.encode_dataset(base, ds, 32, 7)
+        monkeypatch.setenv("KEMR_PRECISION", precision)
+        model, _ = clip.load("ViT-B/32", device="cuda")
+        assert model.engine().precision == precision
+        img, qry, _, _ = evaluators.encode_dataset(model, ds, 32, 7)
+    tol = {"bf16-res16": 1e-3, "fp8": 5e-3, "fp8-mlp": 2e-2}[precision]
+    di, dq = float((1 - _cos(img, ref_img)).max()), float((1 - _cos(qry, ref_qry)).max())
+    assert 0 < di < tol and 0 < dq < tol
+
+
 def test_config2_fused_scoring_cli(device, tmp_path):
     """BASELINE configs[2] plumbing (scripts/fusion/eval.sh -> evaluator_baseline) on a checkpoint file."""
     from knowledge_enhanced_multimodal_retrieval_amd import clip_api, clip_model
