@@ -55,6 +55,9 @@ def default_tokenize(texts: Sequence[str]) -> torch.Tensor:
     return tokenize(list(texts), truncate=True)
 
 
+ENCODE_ITEMS = 255          # items per encoder call in encode_dataset (see there)
+
+
 @torch.no_grad()
 def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_workers: int = 0,
                    tokenize_fn: Optional[Callable] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, List[str]]:
@@ -69,11 +72,31 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
                         worker_init_fn=seed_worker if num_workers else None, generator=g)
     img, qry, tgt, uuids = [], [], [], []
     logger.info(f"Computing embeddings for {len(dataset)} samples...")
+    # The loader's batch size is the host pipeline's business (the reference scripts pass 64); the encoders are fed
+    # ENCODE_ITEMS items at a time whatever it is: 255 images are 65 535 token rows = 256 row tiles of the persistent GEMM,
+    # while e.g. 64 images are 65 row tiles -> 260 tiles on 256 CUs, a second round for 4 tiles.  Rows are independent,
+    # so the embeddings do not depend on the grouping.
+    pend_i, pend_q, pend_t, pending = [], [], [], 0
+
+    def flush():
+        nonlocal pending
+        if not pending:
+            return
+        img.append(model.encode_image(torch.cat(pend_i), normalize=True))
+        qry.append(model.encode_text(torch.cat(pend_q), normalize=True))
+        tgt.append(model.encode_text(torch.cat(pend_t), normalize=True))
+        pend_i.clear(); pend_q.clear(); pend_t.clear()
+        pending = 0
+
     for images, queries, targets, ids in loader:
-        img.append(model.encode_image(images.to(device, non_blocking=True), normalize=True))
-        qry.append(model.encode_text(tokenize_fn(queries).to(device, non_blocking=True), normalize=True))
-        tgt.append(model.encode_text(tokenize_fn(targets).to(device, non_blocking=True), normalize=True))
+        pend_i.append(images.to(device, non_blocking=True))
+        pend_q.append(tokenize_fn(queries).to(device, non_blocking=True))
+        pend_t.append(tokenize_fn(targets).to(device, non_blocking=True))
+        pending += images.shape[0]
         uuids.extend(ids)
+        if pending >= ENCODE_ITEMS:
+            flush()
+    flush()
     return torch.cat(img), torch.cat(qry), torch.cat(tgt), uuids
 
 
