@@ -146,9 +146,9 @@ def test_gemm_skinny(device, m, n, k, epi):
             engine.set_gemm_variant(0)
 
 
-@pytest.mark.parametrize("m,n,k", [(64 * 257, 1024, 1024), (64 * 257, 3072, 1024), (128 * 257, 1024, 512), (256 * 70 + 100, 1024, 256)])
+@pytest.mark.parametrize("m,n,k", [(64 * 257, 1024, 1024), (64 * 257, 3072, 1024), (128 * 257, 1024, 512), (256 * 70 + 100, 1024, 256), (200 * 257, 1024, 256)])
 def test_gemm_ragged_tail_split(device, m, n, k):
-    """Automatic choice only: a last row tile of <= 128 rows that would add a round to the persistent kernel is computed by
+    """Automatic choice only: a ragged last row tile that would add a round to the persistent kernel is computed by
     the skinny kernel (two launches); same results, pad rows aside."""
     for epi in (_lib.EPI_BIAS_BF16, _lib.EPI_BIAS_QGELU_BF16):
         _gemm_epilogue_case(device, m, n, k, epi)
