@@ -44,7 +44,9 @@ class CLIPEvalDatasetHF(Dataset):
         except Exception as e:  # undecodable image -> zero image, like the reference (clip_dataset.py:120-125)
             logger.error(f"Error loading image {sample.get('uuid', idx)}: {e}")
             if self.preprocessor:
-                image = torch.zeros(3, self.image_size, self.image_size)
+                from .preprocess import RawRGB
+                image = (torch.zeros(self.image_size, self.image_size, 3, dtype=torch.uint8) if isinstance(self.preprocessor, RawRGB)
+                         else torch.zeros(3, self.image_size, self.image_size))
             else:
                 from PIL import Image
                 image = Image.new("RGB", (self.image_size, self.image_size))
@@ -82,6 +84,8 @@ class SyntheticRetrievalDataset(Dataset):
 
 def collate_fn_eval(batch):
     images, queries, targets, uuids = zip(*batch)
+    if torch.is_tensor(images[0]) and images[0].dtype == torch.uint8:      # raw [H, W, 3] images of any size (preprocess.RawRGB):
+        return list(images), list(queries), list(targets), list(uuids)    # preprocessed on the GPU by encode_dataset
     return torch.stack(images, dim=0), list(queries), list(targets), list(uuids)
 
 

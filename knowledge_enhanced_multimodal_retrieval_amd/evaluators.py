@@ -88,11 +88,17 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
         pend_i.clear(); pend_q.clear(); pend_t.clear()
         pending = 0
 
+    gpu_pre = None
     for images, queries, targets, ids in loader:
+        if isinstance(images, list):           # raw uint8 images (preprocess.RawRGB): resize / crop / normalise on the device
+            if gpu_pre is None:
+                from .preprocess import ClipPreprocessGPU
+                gpu_pre = ClipPreprocessGPU(int(getattr(getattr(model, "visual", None), "input_resolution", 224)), device)
+            images = torch.stack([gpu_pre(im) for im in images])
         pend_i.append(images.to(device, non_blocking=True))
         pend_q.append(tokenize_fn(queries).to(device, non_blocking=True))
         pend_t.append(tokenize_fn(targets).to(device, non_blocking=True))
-        pending += images.shape[0]
+        pending += int(images.shape[0])
         uuids.extend(ids)
         if pending >= ENCODE_ITEMS:
             flush()

@@ -72,3 +72,15 @@ class ClipPreprocessGPU:
 
     def __repr__(self):
         return f"ClipPreprocessGPU(n_px={self.n_px})"
+
+
+class RawRGB:
+    """Dataset-side half of GPU preprocessing: a PIL image -> uint8 ``[H, W, 3]`` tensor, nothing else.  Give it to a
+    dataset as its ``preprocessor`` and ``evaluators.encode_dataset`` runs :class:`ClipPreprocessGPU` on the device: the
+    DataLoader workers then only decode, the resize / crop / normalise leaves the host (bit-identical result)."""
+
+    def __call__(self, image) -> torch.Tensor:
+        return torch.from_numpy(np.asarray(image.convert("RGB"), dtype=np.uint8).copy())
+
+    def __repr__(self):
+        return "RawRGB()"

@@ -60,3 +60,23 @@ def test_gpu_transform_other_resolution_and_errors(device):
         ClipPreprocessGPU(224, device)(torch.zeros(10, 10, 3))
     with pytest.raises(RuntimeError, match="GPU"):
         ClipPreprocessGPU(224, "cpu")
+
+
+@pytest.mark.gpu
+def test_encode_dataset_with_gpu_preprocessing_is_identical(device):
+    """A dataset that hands out raw uint8 images (preprocess.RawRGB) is preprocessed on the device by encode_dataset: the
+    embeddings equal those of the host transform bit for bit (same pixels in, deterministic kernels)."""
+    import warnings
+    from PIL import Image
+    import clip
+    from knowledge_enhanced_multimodal_retrieval_amd import datasets, evaluators
+    from knowledge_enhanced_multimodal_retrieval_amd.preprocess import RawRGB
+    sizes = [(300, 400), (224, 224), (500, 333), (231, 229), (640, 480), (100, 80), (225, 224)]
+    rows = [{"image": Image.fromarray(_image(h, w, i)), "query_text": f"vase {i} bronze", "target_text": f"bronze vase number {i}",
+             "uuid": f"u{i}"} for i, (h, w) in enumerate(sizes)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model, preprocess = clip.load("ViT-B/32", device="cuda")
+        host = evaluators.encode_dataset(model, datasets.CLIPEvalDatasetHF(rows, preprocess), 3, 1)
+        raw = evaluators.encode_dataset(model, datasets.CLIPEvalDatasetHF(rows, RawRGB()), 3, 1)
+    assert torch.equal(host[0], raw[0]) and torch.equal(host[1], raw[1]) and host[3] == raw[3]
