@@ -78,15 +78,17 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
     # so the embeddings do not depend on the grouping.
     pend_i, pend_q, pend_t, pending = [], [], [], 0
 
-    def flush():
+    def flush(final: bool):
         nonlocal pending
-        if not pending:
+        take = pending if final else (pending // ENCODE_ITEMS) * ENCODE_ITEMS      # whole encoder calls; the rest waits
+        if take <= 0:
             return
-        img.append(model.encode_image(torch.cat(pend_i), normalize=True))
-        qry.append(model.encode_text(torch.cat(pend_q), normalize=True))
-        tgt.append(model.encode_text(torch.cat(pend_t), normalize=True))
-        pend_i.clear(); pend_q.clear(); pend_t.clear()
-        pending = 0
+        ci, cq, ct = torch.cat(pend_i), torch.cat(pend_q), torch.cat(pend_t)
+        img.append(model.encode_image(ci[:take], normalize=True))
+        qry.append(model.encode_text(cq[:take], normalize=True))
+        tgt.append(model.encode_text(ct[:take], normalize=True))
+        pend_i[:], pend_q[:], pend_t[:] = [ci[take:]], [cq[take:]], [ct[take:]]
+        pending -= take
 
     gpu_pre = None
     for images, queries, targets, ids in loader:
@@ -101,8 +103,8 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
         pending += int(images.shape[0])
         uuids.extend(ids)
         if pending >= ENCODE_ITEMS:
-            flush()
-    flush()
+            flush(False)
+    flush(True)
     return torch.cat(img), torch.cat(qry), torch.cat(tgt), uuids
 
 
