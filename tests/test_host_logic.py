@@ -204,7 +204,7 @@ def test_text2sparql_results_loader(tmp_path, monkeypatch):
 
 
 def test_cli_flags_match_reference_scripts():
-    """scripts/baselines/*.sh and scripts/fusion/eval.sh pass these flags (incl. --splits_file, which the reference's
+    """The reference's scripts/baselines/*.sh and scripts/fusion/eval.sh (and scripts/run_eval.sh here) pass these flags (incl. --splits_file, which the reference's
     evaluator_baseline does not declare)."""
     import argparse
     from knowledge_enhanced_multimodal_retrieval_amd import evaluators
