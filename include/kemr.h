@@ -227,6 +227,9 @@ int kemr_preprocess_u8(const unsigned char* img_dev, int height, int width, int 
  * one K-tile pipeline across tiles, non-temporal C stores (2-7 need N % 256 == 0; 4-7 the bf16 epilogues), 8 = skinny-M split-K
  * (default up to 512 rows, bf16 epilogues), 9 = persistent, 4 waves x 128x128, register-staged operands; A/B and tests */
 int kemr_set_gemm_variant(int variant);
+/* tools/ only: cycle sums the persistent GEMM's diagnostic instantiation left behind (variant flag bit 14): 16 words per
+ * workgroup = 8 barrier intervals of the K loop, K-loop tail, epilogue, tiles, K-tiles per tile.  Synchronises the device. */
+int kemr_debug_gemm_stamps(unsigned* host_out, int n_words);
 int kemr_op_gemm(const void* a_dev, const void* w_dev, const float* bias_dev, void* c_dev,
                  int m, int n, int k, int epilogue, void* stream);
 int kemr_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, void* y_dev,

@@ -59,6 +59,7 @@ SIGNATURES = {
     "kemr_profile_begin": (_i, [_i]),
     "kemr_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i64), _i]),
     "kemr_set_gemm_variant": (_i, [_i]),
+    "kemr_debug_gemm_stamps": (_i, [_vp, _i]),
     "kemr_op_gemm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "kemr_preprocess_workspace_bytes": (_sz, [_i, _i, _i]),
     "kemr_preprocess_u8": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),

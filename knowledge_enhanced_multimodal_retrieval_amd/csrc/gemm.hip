@@ -168,6 +168,7 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
 
 int g_gemm_variant = 0;
 int g_gemm_dbg = 0;
+int g_gemm_order = 0;
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     if (p.M <= 0) return KEMR_OK;
@@ -181,13 +182,14 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     const bool bf16_epi = epi == EPI_BIAS_BF16 || epi == EPI_BIAS_QGELU_BF16;
     // a handful of rows (one or a few online queries): 6-24 tiles would leave the chip idle; split K inside the workgroup
     if (bf16_epi && p.c_rows_padded && (g_gemm_variant == 8 || (g_gemm_variant == 0 && p.M <= 512))) return launch_gemm_skinny(p, epi, stream);
+    if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 10) return launch_gemm256u1(p, epi, stream);
     if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 5) return launch_gemm256q(p, epi, stream);
     if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 6) return launch_gemm256w(p, epi, stream);
     if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 9) return launch_gemm256r(p, epi, stream);
     // A ragged last row tile that would cost the persistent kernel one more round over all its workgroups (64 images are
     // 64 x 256 + 64 token rows: 260 tiles of an N = 1024 GEMM on 256 CUs) goes to the skinny kernel instead: measured 4 406 ->
     // 5 320 images/s at 64 images per call (5 650 at 63).
-    if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 0 && p.M > 512) {
+    if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 0 && p.M > 512 && gemm256u_fits(p, 2)) {
         static int ncu = 0;
         if (!ncu) {
             int dev = 0;
@@ -207,7 +209,7 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
         }
     }
     if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 4) return launch_gemm256p(p, epi, stream);
-    if (can256 && bf16_epi && p.c_rows_padded && (g_gemm_variant == 7 || (g_gemm_variant == 0 && tiles256 >= 128)))
+    if (can256 && bf16_epi && p.c_rows_padded && (g_gemm_variant == 7 || (g_gemm_variant == 0 && tiles256 >= 128)) && gemm256u_fits(p, 2))
         return launch_gemm256u(p, epi, stream);
     if (can256 && (g_gemm_variant >= 2 || (g_gemm_variant == 0 && tiles256 >= 128))) return launch_gemm256(p, epi, stream);
     switch (epi) {

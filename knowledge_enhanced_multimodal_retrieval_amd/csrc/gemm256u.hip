@@ -1,16 +1,47 @@
-// Persistent bf16 GEMM for the bf16-output epilogues, 8 waves x (128 x 64), the staggered K loop of gemm256p.hip with ONE
-// K-tile pipeline that runs across output tiles ("uniform"): the LDS-DMA pieces staged during K-tile g belong to K-tiles
-// g+1 (W1, A0, A1) and g+2 (W0) of the workgroup's whole tile sequence, so the first K-tiles of the next output tile
-// are already in LDS when this tile's last MFMA retires, and a tile switch is just: epilogue (16 stores per lane), zero
-// the accumulators, carry on.  gemm256p.hip paid a prologue per tile (issue 16 pieces, wait for K-tile 0: ~2.6 us x 12-16
-// tiles per workgroup on the encoder shapes).
+// Persistent bf16 / fp8 GEMM for the bf16-output epilogues: one 512-thread workgroup (8 waves x (128 x 64)) per CU walks
+// 256 x 256 output tiles with ONE K-tile pipeline that runs across output tiles: the LDS-DMA pieces staged during K-tile g
+// belong to K-tiles g+1 (A0, A1, W1) and g+2 (W0) of the workgroup's whole tile sequence, so the first K-tiles of the next
+// output tile are already in LDS when this tile's last MFMA retires, and a tile switch is just: epilogue (16 stores per
+// lane), carry on (the first MFMA of every accumulator takes the bias as its C operand: no accumulator initialisation).
+//
+// Round 2, from in-kernel stamps (DBG instantiation, tools/bench_gemm_r2.py).  The two wave halves (wr = 0 / 1) run one
+// barrier interval apart for the whole launch, so a SIMD alternates one wave's 16-MFMA cluster (256 cycles) with its
+// partner's load interval, and an interval lasts as long as the longer of the two.  What a load interval costs is the
+// number of instructions the wave has to issue in it (about 4 cycles each) plus 60-100 cycles per LDS-DMA piece: round 1's
+// first interval (12 ds_read_b128, 2 pieces and the ~60 scalar instructions of the K-tile bookkeeping) took ~470 cycles,
+// its 4- and 8-read intervals ~270-330.  Now:
+//  * clusters are split along k instead of along the W columns, so no interval has more than 8 reads:
+//      L1: W(k 0-31) + A rows 0-63 (k 0-31), stage A0(g+1)      M1: acc[rows 0-63]   += . (k 0-31)
+//      L2: W(k 32-63) + A rows 0-63 (k 32-63), stage A1(g+1)    M2: acc[rows 0-63]   += . (k 32-63)
+//      L3: A rows 64-127 (both k halves), stage W1(g+1)         M3: acc[rows 64-127] += . (k 0-31)
+//      L4: stage W0(g+2); wait for K-tile g+1                   M4: acc[rows 64-127] += . (k 32-63) + bookkeeping
+//    (every accumulator still sums k 0-31 before k 32-63 of each K-tile: bit-identical to round 1); the piece with the
+//    shortest flight time (3 intervals) is a W half, which the tile order keeps L2-resident, instead of an A half;
+//  * the K-tile bookkeeping is two pointer streams (A: K-tile g+1, W: K-tile g+2) advanced by 128 bytes, issued two or
+//    three scalar instructions at a time BETWEEN the MFMAs of M4; a stream computes a tile's coordinates once, when the W
+//    stream enters it, and hands them down (W -> A -> epilogue).
+// fp8 operands keep the round-1 clusters (one K = 128 MFMA per K-tile has no k halves to split) on the same staging plan.
+//
+// LDS regions and who reads them: a wave reads W from the half that holds its 64 columns (in L1 and L2) and A from its own
+// row half (L1-L3); a region may be re-staged once BOTH wave halves are past their last read of it and have waited for the
+// data (the lgkmcnt(0) in front of the next cluster) and a barrier lies in between: W0 of this K-tile's buffer from the
+// wr == 0 half's L4 on; the other buffer (K-tile g+1) was last read a K-tile ago.
 //
 // vmcnt (loads, LDS-DMA and stores retire in order): the wait that closes K-tile g needs K-tile g+1 landed and may leave
 // W0(g+2) (2 pieces per lane) in flight: vmcnt(2), or vmcnt(0) when nothing was staged behind it.  The 16 stores of a
-// tile sit between W0(g+2) and W1(g+2) in that order, so they get one K-tile of time before a wait covers them.
-// The next tile's 256 bias floats ride with its first W0 piece (wave 0) into the other half of a 2 x 1 KiB LDS area;
-// the epilogue reads bias and staging area with asm LDS ops (no memory operand, so hipcc adds no vmcnt(0) for them).
+// tile sit between W0(g+2) and A0(g+2) in that order, so they get one K-tile of time before a wait covers them.
+// The next tile's 256 bias floats ride with its first W0 piece (wave 0) into the other half of a 2 x 1 KiB LDS area.
+//
+// Epilogue: 8 passes of 16 rows through LDS (acc -> act -> bf16 -> ds_write_b64, chunk-XOR swizzled -> ds_read_b128 -> one
+// full 128-byte line per 8 lanes, non-temporal), double-buffered: the two wave halves never run their epilogues at the
+// same time (they are separated by the barriers on either side), so a wave alternates between its own 2 KiB area and its
+// partner's (wid ^ 4) and the LDS round trip of pass mi + 1 hides behind the stores of pass mi.  (Stamps: 3 300 cycles per
+// wave half and tile for the single-buffered form, 4 400 for a register-only form with v_permlane16_swap and 64-byte row
+// segments per store instruction - the full-line form is the one to keep.)
 #include "common.h"
+#include <type_traits>
+// (hipcc misses odr-uses inside asm operands of generic lambdas: the hooks below name their captures, which it then calls unused)
+#pragma clang diagnostic ignored "-Wunused-lambda-capture"
 
 namespace kemr {
 
@@ -23,23 +54,13 @@ constexpr int PBIAS = PEPI + 16384;   // 2 x 1 KiB: fp32 bias of the current / n
 constexpr int PSCALE = PBIAS + 2048;  // fp8 operands: 2 x 1 KiB per-output-channel weight scales of the current / next tile
 constexpr int PSMEM = PSCALE + 2048;
 
-__device__ __forceinline__ void glds16u(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// Epilogue LDS traffic as inline asm: hipcc (SIInsertWaitcnts) guards every LDS access that carries a memory operand
-// with `s_waitcnt vmcnt(0)` while an LDS-DMA is outstanding, which would drain the next tile's prefetch.  The wave-
-// private epilogue area is never a DMA target, so no such wait is needed; asm LDS ops carry no memory operand.
+// Epilogue / bias LDS traffic as inline asm: hipcc (SIInsertWaitcnts) guards every LDS access that carries a memory operand
+// with `s_waitcnt vmcnt(0)` while an LDS-DMA is outstanding, which would drain the prefetch.  These areas are never a DMA
+// target of an in-flight piece when they are read, so no such wait is needed; asm LDS ops carry no memory operand.
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
-}
-__device__ __forceinline__ void lds_write_b64(unsigned addr, u32x2 v) {
-    // the trailing s_nop keeps hipcc from overwriting the data registers while the LDS unit still reads them (observed:
-    // a packed VALU op right behind the asm store corrupted the second data dword; cdna guide 5.7 item 1, "Stores")
-    asm volatile("ds_write_b64 %0, %1\n\ts_nop 2" :: "v"(addr), "v"(v) : "memory");
 }
 __device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
     u32x4 d;
@@ -47,43 +68,73 @@ __device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
     return d;
 }
 
-template <int MH, int NH>
-__device__ __forceinline__ void quad(f32x4 (&acc)[8][4], const bf16x8 (&af)[4][2], const bf16x8 (&wf)[2][2]) {
+template <int I> struct HookAt { static constexpr int value = I; };
+
+// 16 MFMAs: rows MH*64 .. +63 of the wave's tile x its 64 columns x one 32-wide k step.  FIRST: the accumulators' first
+// product of a tile, C = the bias quad of the column group (a lane's acc[mi][ni] covers columns ni*16 + lq*4 .. +3 for every
+// mi).  hook(HookAt<i>) runs after the i-th MFMA: a few scalar instructions issue for free while the matrix pipe is busy.
+template <int MH, bool FIRST, class Hook>
+__device__ __forceinline__ void cluster(f32x4 (&acc)[8][4], const bf16x8 (&af)[4], const bf16x8 (&wf)[4], const u32x4 (&b4)[4],
+                                        Hook&& hook) {
     __builtin_amdgcn_s_setprio(1);
     asm volatile("s_nop 1" ::: "memory");      // any compiler VALU write just above -> first asm MFMA operand read
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
-                             : "+v"(acc[MH * 4 + mi][NH * 2 + ni]) : "v"(wf[ni][kk]), "v"(af[mi][kk]));
+    auto step = [&](auto mi_c, auto ni_c) {
+        constexpr int mi = decltype(mi_c)::value, ni = decltype(ni_c)::value;
+        if constexpr (FIRST)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3"
+                         : "=&v"(acc[MH * 4 + mi][ni]) : "v"(wf[ni]), "v"(af[mi]), "v"(b4[ni]));
+        else
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                         : "+v"(acc[MH * 4 + mi][ni]) : "v"(wf[ni]), "v"(af[mi]));
+        hook(HookAt<mi * 4 + ni>{});
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    step(I0{}, I0{}); step(I0{}, I1{}); step(I0{}, I2{}); step(I0{}, I3{});
+    step(I1{}, I0{}); step(I1{}, I1{}); step(I1{}, I2{}); step(I1{}, I3{});
+    step(I2{}, I0{}); step(I2{}, I1{}); step(I2{}, I2{}); step(I2{}, I3{});
+    step(I3{}, I0{}); step(I3{}, I1{}); step(I3{}, I2{}); step(I3{}, I3{});
     __builtin_amdgcn_s_setprio(0);
+    // the fragment reads the hooks issued (asm ds_read: hipcc does not count them) have returned before the wave arrives at the
+    // barrier behind this cluster: that orders them in front of any re-staging of the region and in front of their use
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 // fp8 (OCP e4m3) operands: one block-scaled MFMA covers K = 128 (a lane holds 32 consecutive k bytes of its row), at twice
 // the bf16 MFMA's cycles, i.e. twice the FLOP rate; the E8M0 block scales are all 2^0 (0x7f), the real scales (one per
 // output channel of W) are applied in the epilogue.  A K-tile is still 128 bytes per row: staging, LDS image and swizzle
-// are the bf16 kernel's, a fragment is two adjacent 16-byte chunks instead of one.
+// are the bf16 kernel's, a fragment is two adjacent 16-byte chunks instead of one.  8 MFMAs (of 32 cycles) per quadrant.
 typedef __attribute__((ext_vector_type(8))) int fp8x32;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
-template <int MH, int NH>
-__device__ __forceinline__ void quad8(f32x4 (&acc)[8][4], const fp8x32 (&af)[4], const fp8x32 (&wf)[2], int one) {
+template <int MH, int NH, bool FIRST, class Hook>
+__device__ __forceinline__ void quad8(f32x4 (&acc)[8][4], const fp8x32 (&af)[4], const fp8x32 (&wf)[2], int one, Hook&& hook) {
     __builtin_amdgcn_s_setprio(1);
     asm volatile("s_nop 1" ::: "memory");
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+    auto step = [&](auto mi_c, auto ni_c) {
+        constexpr int mi = decltype(mi_c)::value, ni = decltype(ni_c)::value;
+        if constexpr (FIRST)
+            asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]"
+                         : "=&v"(acc[MH * 4 + mi][NH * 2 + ni]) : "v"(wf[ni]), "v"(af[mi]), "v"(one));
+        else
             asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
                          : "+v"(acc[MH * 4 + mi][NH * 2 + ni]) : "v"(wf[ni]), "v"(af[mi]), "v"(one));
+        hook(HookAt<2 * (mi * 2 + ni)>{});
+        hook(HookAt<2 * (mi * 2 + ni) + 1>{});
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    step(I0{}, I0{}); step(I0{}, I1{}); step(I1{}, I0{}); step(I1{}, I1{});
+    step(I2{}, I0{}); step(I2{}, I1{}); step(I3{}, I0{}); step(I3{}, I1{});
     __builtin_amdgcn_s_setprio(0);
 }
 
 }  // namespace
 
-template <int EPI, bool FP8, bool AFIRST, bool DBG = false>
+__device__ unsigned g_gemm_stamp_buf[1024 * 16];      // DBG stamps: [workgroup][16]
+
+constexpr int GEMM256U_MAX_TILES_PER_WG = 62;         // the tile table is one lane per tile (+ 2 dummies behind the last)
+
+template <int EPI, bool FP8, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmParams p) {
     constexpr int ES = FP8 ? 1 : 2;          // operand element size
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -92,71 +143,127 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     const int wr = wid >> 2, wc = wid & 3;
 
     const int tiles_n = p.N >> 8;
-    const int ntiles = ((p.M + 255) >> 8) * tiles_n;
-    const int full = (ntiles / (int)gridDim.x) * (int)gridDim.x;     // tiles inside complete rounds
-    auto tile_of = [&](int idx, int& row0, int& col0) {              // XCD-contiguous order, as gemm256p.hip
+    const int tiles_m = (p.M + 255) >> 8;
+    const int ntiles = tiles_m * tiles_n;
+    const int G = (int)gridDim.x;
+    const int full = (ntiles / G) * G;                               // tiles inside complete rounds
+    // Tile order.  Blocks with equal blockIdx % 8 share an XCD (observed round-robin placement; speed only), and every XCD
+    // has its own 4 MiB L2.  Within a round the G / 8 workgroups of an XCD take G / 8 consecutive positions of the order
+    // below; a position is mapped to a tile so that these form a block of (G / 8 / cw) row tiles x cw column tiles, and an
+    // XCD's consecutive rounds stay in the same column group: its cw W panels stay L2-resident while the A panels stream
+    // (p.order = log2(cw) + 1; 0 = the round-1 order, N fastest: an XCD then cycles through ALL of W every round).
+    const int lgcw = p.order - 1;
+    auto tile_of = [&](int idx, int& row0, int& col0) {
         int L = idx;
-        if (idx < full && (gridDim.x & 7) == 0) {
-            const int rnd = idx / (int)gridDim.x, b = idx - rnd * (int)gridDim.x;
-            L = rnd * (int)gridDim.x + (b & 7) * ((int)gridDim.x >> 3) + (b >> 3);
+        const int per = G >> 3;
+        if (idx < full && (G & 7) == 0) {
+            const int rnd = idx / G, b = idx - rnd * G;
+            L = rnd * G + (b & 7) * per + (b >> 3);
         }
-        const int tm = L / tiles_n;
+        int tm, tn;
+        if (lgcw >= 0 && (G & 7) == 0 && per >= (1 << lgcw) && (per & ((1 << lgcw) - 1)) == 0) {
+            const int cw = 1 << lgcw, rh = per >> lgcw;
+            const int RM = (tiles_m / rh) * rh, CN = tiles_n & ~(cw - 1);
+            const int nsup = RM * CN;
+            if (L < nsup) {
+                const int beta = L / per, within = L - beta * per;
+                const int nrb = RM / rh;
+                const int cg = beta / nrb, rb = beta - cg * nrb;
+                tm = rb * rh + (within >> lgcw);
+                tn = (cg << lgcw) + (within & (cw - 1));
+            } else {
+                int r = L - nsup;
+                const int wdt = tiles_n - CN, strip = wdt * RM;      // right strip (rows < RM, columns >= CN), then the bottom rows
+                if (r < strip) { tm = r / wdt; tn = CN + (r - tm * wdt); }
+                else { r -= strip; tm = RM + r / tiles_n; tn = r - (tm - RM) * tiles_n; }
+            }
+        } else {
+            tm = L / tiles_n;
+            tn = L - tm * tiles_n;
+        }
         row0 = tm << 8;
-        col0 = (L - tm * tiles_n) << 8;
+        col0 = tn << 8;
     };
-    const int nt = FP8 ? p.K >> 7 : p.K >> 6;      // K-tile = 128 bytes per row
-    // Order of the three pieces of K-tile g+1 staged during K-tile g.  Long K (fc2: A is the 0.5 GB MLP hidden, streamed
-    // from HBM, 4 tiles per A panel): the A halves first, a full K-tile ahead of their use, then W1 (measured, sustained:
-    // 470 -> 443 us at K = 4096).  Short K (A panels shared by 12-16 column tiles, mostly L2 hits): W1, A0, A1 spread over
-    // the first three intervals is 1 % faster.
-    // (a template parameter: a run-time branch at the three staging sites of this loop costs several per cent)
-    constexpr bool afirst = AFIRST;
+    const int nt = FP8 ? p.K >> 7 : p.K >> 6;      // K-tile = 128 bytes per row; nt >= 2
 
-    // staging addresses = wave-uniform K-tile base (SGPRs) + a per-lane 32-bit byte offset that never changes
+    // ---- the workgroup's tile table: lane s = its s-th tile (tile index blockIdx + s * G), computed ONCE with vector
+    // arithmetic; the scalar side fetches an entry with v_readlane when a stream enters a tile, so the K loop has no tile
+    // arithmetic and no branch.  Lanes behind the last tile hold tile (0, 0): the pointer streams run two K-tiles past the
+    // end and stage (valid, unused) data instead of being switched off.
+    const int ntl = (ntiles - (int)blockIdx.x + G - 1) / G;          // tiles of this workgroup, <= GEMM256U_MAX_TILES_PER_WG (host)
+    int t_row = 0, t_col = 0;
+    {
+        const int tidx = (int)blockIdx.x + lane * G;
+        if (tidx < ntiles) tile_of(tidx, t_row, t_col);
+    }
+    const unsigned v_aoff = (unsigned)t_row * (unsigned)(p.lda * ES);          // byte offsets (< 4 GiB: host check)
+    const unsigned v_woff = (unsigned)t_col * (unsigned)(p.ldw * ES);
+    const unsigned v_coff = ((unsigned)t_row * (unsigned)p.ldc + (unsigned)t_col) * 2u;
+    const int v_bcol = t_col;
+
+    // staging addresses = wave-uniform K-tile pointer (SGPRs) + a per-lane 32-bit byte offset that never changes
     const int srow = lane >> 3, schunk = lane & 7;
     const int r0 = wid * 16 + srow, r1 = r0 + 8;
     const unsigned a_lane0 = (unsigned)(r0 * p.lda * ES + ((schunk ^ ((r0 >> 1) & 7)) << 4));
     const unsigned a_lane1 = (unsigned)(r1 * p.lda * ES + ((schunk ^ ((r1 >> 1) & 7)) << 4));
     const unsigned w_lane0 = (unsigned)(r0 * p.ldw * ES + ((schunk ^ ((r0 >> 1) & 7)) << 4));
     const unsigned w_lane1 = (unsigned)(r1 * p.ldw * ES + ((schunk ^ ((r1 >> 1) & 7)) << 4));
-    const size_t a_half = (size_t)128 * p.lda * ES, w_half = (size_t)128 * p.ldw * ES;      // bytes between the two half-tiles
-    char* const stage_base = smem + wid * 2048;
 
-    // a K-tile of the workgroup's tile sequence (all wave-uniform)
-    struct Cur { const char* a; const char* w; int idx, tau, par, seq, col0; bool valid; };
-    auto cur_set = [&](Cur& c) {
-        int row0, col0;
-        tile_of(c.idx, row0, col0);
-        c.a = (const char*)p.A + (size_t)row0 * p.lda * ES;
-        c.w = (const char*)p.W + (size_t)col0 * p.ldw * ES;
-        c.col0 = col0;
+    // ---- two streams run ahead of the computing K-tile g of the workgroup's K-tile sequence: the A stream at K-tile g+1
+    // (staged in L1 / L2), the W stream at g+2 (staged in L3 / L4).  A stream is a 32-bit byte offset into its matrix (tile
+    // offset from the table + 128 bytes per K-tile), t* = K-tiles left in the stream's tile including the one it points at,
+    // seq* = the tile's position in the table.
+    int tw = nt, seqw = 0, ta = nt, seqa = 0;
+    unsigned ow = __builtin_amdgcn_readlane(v_woff, 0), oa = __builtin_amdgcn_readlane(v_aoff, 0);
+    const unsigned a_half = 128u * (unsigned)(p.lda * ES), w_half = 128u * (unsigned)(p.ldw * ES);     // bytes between the two half-tiles
+    unsigned ow1 = ow + w_half, oa1 = oa + a_half;
+    // one advance, branch-free, in five steps (inside the K loop one step per MFMA gap, see the hooks):
+    //   1 --t; wrapped = t == 0; t = wrapped ? nt : t; seq += wrapped     (SCC carries `wrapped` into the s_addc)
+    //   2 tile offset of table entry seq   3 offset + 128   4 pick by t == nt (true only right after a wrap)   5 second half
+#define KEMR_STREAM_STEP1(T, SEQ) asm volatile("s_sub_i32 %0, %0, 1\n\ts_cmp_eq_u32 %0, 0\n\ts_cselect_b32 %0, %2, %0\n\ts_addc_u32 %1, %1, 0" \
+                                               : "+s"(T), "+s"(SEQ) : "s"(nt) : "scc")
+    unsigned toff_a = 0, toff_w = 0, inc_a = 0, inc_w = 0;
+    auto advance_w = [&]() {
+        KEMR_STREAM_STEP1(tw, seqw);
+        toff_w = __builtin_amdgcn_readlane(v_woff, seqw);
+        inc_w = ow + 128;
+        ow = tw == nt ? toff_w : inc_w;
+        ow1 = ow + w_half;
     };
-    auto cur_next = [&](Cur& c) {
-        c.par ^= 1;
-        if (++c.tau == nt) {
-            c.tau = 0;
-            c.seq++;
-            c.idx += gridDim.x;
-            c.valid = c.idx < ntiles;
-            if (c.valid) cur_set(c);
+    auto advance_a = [&]() {
+        KEMR_STREAM_STEP1(ta, seqa);
+        toff_a = __builtin_amdgcn_readlane(v_aoff, seqa);
+        inc_a = oa + 128;
+        oa = ta == nt ? toff_a : inc_a;
+        oa1 = oa + a_half;
+    };
+    // LDS-DMA of one 16-row x 128-byte piece per wave: SGPR matrix base + per-lane 32-bit offset -> LDS at M0 + lane * 16.
+    // All LDS-DMA of the kernel goes through this statement (M0 is written in the statement that uses it; the compiler has no
+    // LDS-DMA of its own here whose M0 it could move across).
+#define KEMR_GLDS(VOFF, SBASE, LDSADDR) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" \
+                                                     :: "v"(VOFF), "s"(SBASE), "s"(LDSADDR) : "memory")
+    const unsigned stage_lds = lds_addr(smem) + wid * 2048;
+    auto stage_a = [&](unsigned off, unsigned dst) {
+        const unsigned v0 = a_lane0 + off, v1 = a_lane1 + off;
+        KEMR_GLDS(v0, p.A, dst);
+        KEMR_GLDS(v1, p.A, dst + 1024);
+    };
+    auto stage_w = [&](unsigned off, unsigned dst) {
+        const unsigned v0 = w_lane0 + off, v1 = w_lane1 + off;
+        KEMR_GLDS(v0, p.W, dst);
+        KEMR_GLDS(v1, p.W, dst + 1024);
+    };
+    // With the W1 half of K-tile 0 of a tile: that tile's bias (wave 0).  The bias rides with the LAST piece in front of a
+    // wait-free stretch, so that nobody waits for it straight after issuing it.
+    auto stage_bias = [&]() {
+        if (__builtin_expect(tw == nt, 0)) {
+            if (wid == 0) {
+                const unsigned boff = ((unsigned)__builtin_amdgcn_readlane(v_bcol, seqw) + lane * 4) * 4u;
+                const unsigned dst = lds_addr(smem) + PBIAS + (seqw & 1) * 1024;
+                if (p.bias) KEMR_GLDS(boff, p.bias, dst);
+                if (FP8) KEMR_GLDS(boff, p.wscale, dst + (PSCALE - PBIAS));
+            }
         }
-    };
-    auto stage_a = [&](int half, const Cur& c) {
-        char* dst = stage_base + c.par * PBUF + half * PHALF;
-        const char* src = c.a + half * a_half + c.tau * 128;
-        glds16u(src + a_lane0, dst);
-        glds16u(src + a_lane1, dst + 1024);
-    };
-    auto stage_w = [&](int half, const Cur& c) {
-        char* dst = stage_base + c.par * PBUF + (2 + half) * PHALF;
-        const char* src = c.w + half * w_half + c.tau * 128;
-        glds16u(src + w_lane0, dst);
-        glds16u(src + w_lane1, dst + 1024);
-    };
-    auto stage_w0 = [&](const Cur& c) {       // first piece of a K-tile; with K-tile 0 of a tile: that tile's bias (wave 0)
-        if (c.tau == 0 && wid == 0 && p.bias) glds16u(p.bias + c.col0 + lane * 4, smem + PBIAS + (c.seq & 1) * 1024);
-        if (FP8 && c.tau == 0 && wid == 0) glds16u(p.wscale + c.col0 + lane * 4, smem + PSCALE + (c.seq & 1) * 1024);
-        stage_w(0, c);
     };
 
     const int lrow = lane & 15, lq = lane >> 4;
@@ -167,91 +274,236 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     const int b_off = 2 * PHALF + (wc >> 1) * PHALF + ((wc & 1) * 64 + lrow) * 128;
 
     if (!p.bias && tid < 128) *(float4*)(smem + PBIAS + tid * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
-    // prologue: K-tile 0 complete and W0 of K-tile 1 (nt >= 2, so both belong to the first tile)
-    Cur c1;
-    c1.idx = blockIdx.x; c1.tau = 0; c1.par = 0; c1.seq = 0; c1.valid = true;
-    cur_set(c1);
-    stage_w0(c1); stage_w(1, c1); stage_a(0, c1); stage_a(1, c1);
-    cur_next(c1);                        // c1 = K-tile 1: its W1, A0, A1 are staged during K-tile 0
-    stage_w0(c1);
-    Cur c2 = c1;
-    cur_next(c2);                        // c2 = K-tile 2: its W0 is staged at the end of K-tile 0
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    // prologue: K-tile 0 complete, both W halves of K-tile 1 in flight (nt >= 2, so all of it belongs to the first tile)
+    stage_w(ow, stage_lds + 2 * PHALF);
+    stage_w(ow1, stage_lds + 3 * PHALF);
+    stage_bias();
+    stage_a(oa, stage_lds);
+    stage_a(oa1, stage_lds + PHALF);
+    advance_w();                               // W stream -> K-tile 1
+    advance_a();                               // A stream -> K-tile 1
+    stage_w(ow, stage_lds + PBUF + 2 * PHALF);
+    stage_w(ow1, stage_lds + PBUF + 3 * PHALF);
+    advance_w();                               // W stream -> K-tile 2
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");      // lgkmcnt: the zero-filled bias area (no-bias launches)
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();      // wr == 1 half runs one interval behind for the whole launch
 
-    int gpar = 0, seq = 0;
-    bf16x8 af[4][2], w0[2][2], w1[2][2];          // bf16 operands
+    int gpar = 0;
+    bf16x8 ak0[4], ak1[4], wk0[4], wk1[4];        // bf16 operands: A rows (current 64-row half) / W columns x k step
     fp8x32 af8[4], w08[2], w18[2];                 // fp8 operands (only one set is live, by FP8)
     int one = 0x7f7f7f7f;                          // E8M0 block scales 2^0
     asm volatile("" : "+v"(one));
-    auto ld_w = [&](bf16x8 (&w)[2][2], fp8x32 (&w8)[2], const char* q) {
+    auto ld_w8 = [&](fp8x32 (&w8)[2], const char* q) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            if constexpr (FP8) {
-                w8[ni].lo = *(const i32x4*)(q + ni * 2048 + co0);
-                w8[ni].hi = *(const i32x4*)(q + ni * 2048 + co1);
-            } else {
-                w[ni][0] = *(const bf16x8*)(q + ni * 2048 + co0);
-                w[ni][1] = *(const bf16x8*)(q + ni * 2048 + co1);
-            }
+            w8[ni].lo = *(const i32x4*)(q + ni * 2048 + co0);
+            w8[ni].hi = *(const i32x4*)(q + ni * 2048 + co1);
         }
     };
-    auto ld_a = [&](const char* q) {
+    auto ld_a8 = [&](const char* q) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-            if constexpr (FP8) {
-                af8[mi].lo = *(const i32x4*)(q + mi * 2048 + co0);
-                af8[mi].hi = *(const i32x4*)(q + mi * 2048 + co1);
-            } else {
-                af[mi][0] = *(const bf16x8*)(q + mi * 2048 + co0);
-                af[mi][1] = *(const bf16x8*)(q + mi * 2048 + co1);
+            af8[mi].lo = *(const i32x4*)(q + mi * 2048 + co0);
+            af8[mi].hi = *(const i32x4*)(q + mi * 2048 + co1);
+        }
+    };
+    // bf16 fragment reads as asm, issued from the hooks between MFMAs; LDS byte addresses of the wave's fragment rows in the
+    // buffer the NEXT reads come from (dynamic LDS starts at address 0 and every base is below 64 KiB: ^ PBUF switches buffer)
+    unsigned vb0 = lds_addr(smem) + b_off + co0, vb1 = lds_addr(smem) + b_off + co1;
+    unsigned va0 = lds_addr(smem) + a_off + co0, va1 = lds_addr(smem) + a_off + co1;
+#define KEMR_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"(OFF) : "memory")
+    if constexpr (!FP8) {                          // fragments of the first cluster of K-tile 0
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { KEMR_DSR(wk0[i], vb0, i * 2048); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { KEMR_DSR(ak0[i], va0, i * 2048); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // in-kernel stamps (DBG instantiation; wave 0 only): dbg & 64 = cycles per barrier interval of the K loop + epilogue,
+    // + dbg & 32 = own work before three of the barriers, dbg & 128 alone = whole-kernel cycles and 100 MHz ticks
+    unsigned st_prev = 0, st_slot[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const bool stamping = DBG && (p.dbg & 64) && wid == 0 && p.stamps;
+    auto stamp = [&](int slot) {
+        if constexpr (DBG) {
+            if (stamping) {
+                unsigned long long tt;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
+                const unsigned now = (unsigned)tt;
+                st_slot[slot] += now - st_prev;
+                st_prev = now;
             }
         }
     };
-    for (int idx = blockIdx.x; idx < ntiles; idx += gridDim.x, ++seq) {
-        f32x4 acc[8][4];
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-                asm volatile("" : "+v"(acc[mi][ni]));    // materialise the zeros here (see gemm256p.hip)
+    auto stamp_pre = [&](int slot) {           // time since the last interval stamp, st_prev untouched
+        if constexpr (DBG) {
+            if (stamping && (p.dbg & 32)) {
+                unsigned long long tt;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
+                st_slot[slot] += (unsigned)tt - st_prev;
             }
+        }
+    };
+    unsigned long long clk0 = 0, rt0 = 0;
+    const bool clocking = DBG && (p.dbg & (64 | 128)) && wid == 0 && p.stamps;
+    if constexpr (DBG) {
+        if (clocking) {
+            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0), "=s"(rt0) :: "memory");
+            st_prev = (unsigned)clk0;
+        }
+    }
 
-        for (int t = 0; t < nt; ++t, gpar ^= 1) {
+    f32x4 acc[8][4];
+    u32x4 b4[4];                                   // bf16 operands: the tile's bias quads = C of the first MFMA per accumulator
+    // Hooks: what a wave issues in the gap behind the I-th MFMA of a cluster.  An MFMA holds the SIMD's vector issue for half
+    // of its 16 cycles, so ONE cheap instruction per gap is free and everything beyond it costs its issue time (stamps: a
+    // cluster with 25 extra instructions bunched in its first gaps took 420 cycles instead of 256).  Per K-tile there are 64
+    // gaps for 24 fragment reads and ~25 instructions of stream bookkeeping: at most one action per gap, A stream in M2 (its
+    // offsets were last used in L2), W stream in M4 (last used in L4), behind that cluster's reads.
+    // A pin in front of a step orders it behind the MFMA in front of it, the one behind it in front of the next MFMA.
+    auto step_a = [&](auto at) {
+        constexpr int J = decltype(at)::value;
+        if constexpr (J == 0) { KEMR_STREAM_STEP1(ta, seqa); }
+        if constexpr (J == 1) { asm volatile("" : "+s"(seqa)); toff_a = __builtin_amdgcn_readlane(v_aoff, seqa); asm volatile("" : "+s"(toff_a)); }
+        if constexpr (J == 2) { asm volatile("" : "+s"(oa)); inc_a = oa + 128; asm volatile("" : "+s"(inc_a)); }
+        if constexpr (J == 3) { asm volatile("" : "+s"(inc_a)); oa = ta == nt ? toff_a : inc_a; asm volatile("" : "+s"(oa)); }
+        if constexpr (J == 4) { asm volatile("" : "+s"(oa)); oa1 = oa + a_half; asm volatile("" : "+s"(oa1)); }
+    };
+    auto step_w = [&](auto at) {
+        constexpr int J = decltype(at)::value;
+        if constexpr (J == 0) { KEMR_STREAM_STEP1(tw, seqw); }
+        if constexpr (J == 1) { asm volatile("" : "+s"(seqw)); toff_w = __builtin_amdgcn_readlane(v_woff, seqw); asm volatile("" : "+s"(toff_w)); }
+        if constexpr (J == 2) { asm volatile("" : "+s"(ow)); inc_w = ow + 128; asm volatile("" : "+s"(inc_w)); }
+        if constexpr (J == 3) { asm volatile("" : "+s"(inc_w)); ow = tw == nt ? toff_w : inc_w; asm volatile("" : "+s"(ow)); }
+        if constexpr (J == 4) { asm volatile("" : "+s"(ow)); ow1 = ow + w_half; asm volatile("" : "+s"(ow1)); }
+    };
+    auto nohook = [](auto) {};
+    // every cluster reads the NEXT cluster's fragments (their registers were last used two clusters ago)
+    auto hook_m1 = [&wk1, &ak1, &vb1, &va1](auto at) {                  // M1 (lo rows, k 0-31) -> M2's fragments: W and lo rows, k 32-63
+        constexpr int I = decltype(at)::value;
+        if constexpr (I < 4) { KEMR_DSR(wk1[I], vb1, I * 2048); }
+        else if constexpr (I < 8) { KEMR_DSR(ak1[I - 4], va1, (I - 4) * 2048); }
+    };
+    auto hook_m2 = [&ak0, &va0, &step_a](auto at) {                     // M2 -> M3's fragments: hi rows, k 0-31; A stream
+        constexpr int I = decltype(at)::value;
+        if constexpr (I < 4) { KEMR_DSR(ak0[I], va0, 8192 + I * 2048); }
+        else if constexpr (I >= 5 && I <= 13 && (I & 1)) step_a(HookAt<(I - 5) / 2>{});
+    };
+    auto hook_m3 = [&ak1, &vb0, &vb1, &va0, &va1](auto at) {            // M3 -> M4's fragments: hi rows, k 32-63; then the bases switch buffer
+        constexpr int I = decltype(at)::value;
+        if constexpr (I < 4) { KEMR_DSR(ak1[I], va1, 8192 + I * 2048); }
+        else if constexpr (I == 6) { vb0 ^= PBUF; asm volatile("" : "+v"(vb0)); }
+        else if constexpr (I == 8) { vb1 ^= PBUF; asm volatile("" : "+v"(vb1)); }
+        else if constexpr (I == 10) { va0 ^= PBUF; asm volatile("" : "+v"(va0)); }
+        else if constexpr (I == 12) { va1 ^= PBUF; asm volatile("" : "+v"(va1)); }
+    };
+    // M4 -> the next K-tile's M1 fragments: W and lo rows, k 0-31; W stream (both of its offsets were last used in L4)
+    auto hook_m4 = [&wk0, &ak0, &vb0, &va0, &gpar, &step_w](auto at) {
+        constexpr int I = decltype(at)::value;
+        if constexpr (I < 4) { KEMR_DSR(wk0[I], vb0, I * 2048); }
+        else if constexpr (I < 8) { KEMR_DSR(ak0[I - 4], va0, (I - 4) * 2048); }
+        else if constexpr (I == 8) step_w(HookAt<0>{});
+        else if constexpr (I >= 10 && I <= 13) step_w(HookAt<I - 9>{});
+        else if constexpr (I == 15) { asm volatile("" : "+s"(gpar)); gpar ^= 1; asm volatile("" : "+s"(gpar)); }
+    };
+    // fp8: the reads stay in the load intervals; the streams use the same clusters
+    auto hook8_m2 = [&step_a](auto at) { constexpr int I = decltype(at)::value; if constexpr (I >= 1 && I <= 9 && (I & 1)) step_a(HookAt<(I - 1) / 2>{}); };
+    auto hook8_m4 = [&gpar, &step_w](auto at) {
+        constexpr int I = decltype(at)::value;
+        if constexpr (I >= 1 && I <= 9 && (I & 1)) step_w(HookAt<(I - 1) / 2>{});
+        else if constexpr (I == 11) { asm volatile("" : "+s"(gpar)); gpar ^= 1; asm volatile("" : "+s"(gpar)); }
+    };
+
+    // One K-tile.  LDS-DMA per interval: L1 A0(g+1), L2 A1(g+1), L3 W0(g+2), L4 W1(g+2) [+ bias]; the wait that needs K-tile
+    // g+1 complete sits at the end of M3 (in front of the barrier in front of M4, whose hooks read K-tile g+1) and leaves
+    // W0(g+2) in flight.
+    auto ktile = [&](auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        const unsigned buf_this = stage_lds + gpar * PBUF;
+        const unsigned buf_next = stage_lds + (gpar ^ 1) * PBUF;
+        if constexpr (FP8) {
             const char* sa = smem + gpar * PBUF + a_off;
             const char* sb = smem + gpar * PBUF + b_off;
-            ld_w(w0, w08, sb);
-            ld_a(sa);
-            if (c1.valid) { if (afirst) { stage_a(0, c1); stage_a(1, c1); } else stage_w(1, c1); }
+            ld_w8(w08, sb);
+            ld_a8(sa);
+            stage_a(oa, buf_next);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w08[0]), "+v"(w08[1]), "+v"(af8[0]), "+v"(af8[1]), "+v"(af8[2]), "+v"(af8[3]) :: "memory");
             __builtin_amdgcn_s_barrier();
-            if constexpr (FP8) quad8<0, 0>(acc, af8, w08, one); else quad<0, 0>(acc, af, w0);
+            stamp(0);
+            quad8<0, 0, FIRST>(acc, af8, w08, one, nohook);
             __builtin_amdgcn_s_barrier();
-            ld_w(w1, w18, sb + 4096);
-            if (c1.valid) { if (afirst) stage_w(1, c1); else stage_a(0, c1); }
+            stamp(1);
+            ld_w8(w18, sb + 4096);
+            stage_a(oa1, buf_next + PHALF);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w18[0]), "+v"(w18[1]) :: "memory");     // the reads are done in front of the barrier: W may be re-staged behind the next one
             __builtin_amdgcn_s_barrier();
-            if constexpr (FP8) quad8<0, 1>(acc, af8, w18, one); else quad<0, 1>(acc, af, w1);
+            stamp(2);
+            quad8<0, 1, FIRST>(acc, af8, w18, one, hook8_m2);
             __builtin_amdgcn_s_barrier();
-            ld_a(sa + 8192);
-            if (c1.valid && !afirst) stage_a(1, c1);
+            stamp(3);
+            ld_a8(sa + 8192);
+            stage_w(ow, buf_this + 2 * PHALF);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af8[0]), "+v"(af8[1]), "+v"(af8[2]), "+v"(af8[3]) :: "memory");
             __builtin_amdgcn_s_barrier();
-            if constexpr (FP8) quad8<1, 1>(acc, af8, w18, one); else quad<1, 1>(acc, af, w1);
+            stamp(4);
+            quad8<1, 1, FIRST>(acc, af8, w18, one, nohook);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // K-tile g+1 landed (everything older too, a tile's stores included)
             __builtin_amdgcn_s_barrier();
-            const bool v1 = c1.valid, v2 = c2.valid;
-            if (v2) stage_w0(c2);
-            auto close_tile = [&]() {           // K-tile g+1 landed (everything older too, the last tile's stores included)
-                if (v2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else if (v1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            };
-            if (wr == 1) close_tile();
+            stamp(5);
+            stage_w(ow1, buf_this + 3 * PHALF);
+            stage_bias();
             __builtin_amdgcn_s_barrier();
-            if constexpr (FP8) quad8<1, 0>(acc, af8, w08, one); else quad<1, 0>(acc, af, w0);
-            if (wr == 0) close_tile();
+            stamp(6);
+            quad8<1, 0, FIRST>(acc, af8, w08, one, hook8_m4);
             __builtin_amdgcn_s_barrier();
-            c1 = c2;
-            cur_next(c2);
+            stamp(7);
+        } else {
+            stage_a(oa, buf_next);
+            stamp_pre(10);
+            __builtin_amdgcn_s_barrier();
+            stamp(0);
+            cluster<0, FIRST>(acc, ak0, wk0, b4, hook_m1);
+            stamp_pre(11);
+            __builtin_amdgcn_s_barrier();
+            stamp(1);
+            stage_a(oa1, buf_next + PHALF);
+            __builtin_amdgcn_s_barrier();
+            stamp(2);
+            cluster<0, false>(acc, ak1, wk1, b4, hook_m2);
+            __builtin_amdgcn_s_barrier();
+            stamp(3);
+            stage_w(ow, buf_this + 2 * PHALF);
+            __builtin_amdgcn_s_barrier();
+            stamp(4);
+            cluster<1, FIRST>(acc, ak0, wk0, b4, hook_m3);
+            stamp_pre(12);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // K-tile g+1 landed (everything older too, a tile's stores included)
+            stamp_pre(13);
+            __builtin_amdgcn_s_barrier();
+            stamp(5);
+            stage_w(ow1, buf_this + 3 * PHALF);
+            stage_bias();
+            __builtin_amdgcn_s_barrier();
+            stamp(6);
+            cluster<1, false>(acc, ak1, wk1, b4, hook_m4);
+            __builtin_amdgcn_s_barrier();
+            stamp(7);
         }
+    };
+
+    for (int seq = 0; seq < ntl; ++seq) {
+        if constexpr (!FP8) {
+            // The tile's bias came in with its first W0 piece, which the wait + barrier that closed the previous K-tile (or the
+            // prologue) cover; a lane's accumulators cover columns wc * 64 + ni * 16 + lq * 4 .. + 3.
+            int il = lane;
+            asm volatile("" : "+v"(il));
+            const unsigned bias_r = lds_addr(smem + PBIAS) + (seq & 1) * 1024 + (wc * 64 + (il >> 4) * 4) * 4;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) b4[ni] = lds_read_b128(bias_r + ni * 64);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]) :: "memory");
+        }
+        ktile(std::true_type{});
+        for (int t = 1; t < nt; ++t) ktile(std::false_type{});
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // asm MFMA result -> VALU read (>= 12 wait states)
 
         // ---- epilogue (lane constants behind an opaque copy of `lane`: recomputed here, not kept across the K loop)
@@ -259,87 +511,147 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
         asm volatile("" : "+v"(el));
         const int erow = el & 15, eq = el >> 4;
         const int er = el >> 3, ec = el & 7;                              // read-back: row er (+8), chunk ec
-        const unsigned epi = lds_addr(smem + PEPI) + wid * 2048;          // wave-private: 16 rows x 128 B, chunk ^= row & 7
-        const unsigned c_lane = (unsigned)(er * p.ldc + ec * 8) * 2u;
-        const unsigned epi_w = epi + erow * 128 + (((eq >> 1) ^ (erow & 7)) << 4) + (eq & 1) * 8;
-        const unsigned epi_r0 = epi + er * 128 + ((ec ^ er) << 4);        // rows er and er + 8: (er + 8) & 7 == er
-        const unsigned epi_r1 = epi_r0 + 1024;
-        const unsigned bias_r = lds_addr(smem + PBIAS) + (seq & 1) * 1024 + (wc * 64 + eq * 4) * 4;
-        int row0, col0;
-        tile_of(idx, row0, col0);
-        char* const c_tile = (char*)p.C + ((size_t)(row0 + wr * 128) * p.ldc + col0 + wc * 64) * 2;
+        // 16 rows x 128 B per area, chunk ^= row & 7.  Even passes use the area of wave (wid & 3), odd passes that of wave
+        // (wid & 3) + 4 (8 KiB further): the wave's own and its partner's, which is idle (header)
+        const unsigned epi0 = lds_addr(smem + PEPI) + (wid & 3) * 2048;
+        const unsigned epi_w = epi0 + erow * 128 + (((eq >> 1) ^ (erow & 7)) << 4) + (eq & 1) * 8;
+        const unsigned epi_r = epi0 + er * 128 + ((ec ^ er) << 4);        // rows er and er + 8: (er + 8) & 7 == er
+        const unsigned ew0 = epi_w, ew1 = epi_w ^ 32, ew2 = epi_w ^ 64, ew3 = epi_w ^ 96;      // chunk (ni*2 + (eq>>1)) ^ (erow & 7): ni flips bits 5-6
+        const char* const ctile = (const char*)p.C + __builtin_amdgcn_readlane(v_coff, seq) + ((size_t)(wr * 128) * p.ldc + wc * 64) * 2;     // wave-uniform
+        unsigned voff = (unsigned)(er * p.ldc + ec * 8) * 2u;            // + 16 rows per pass
+        const unsigned step8 = (unsigned)p.ldc * 16u;                     // 8 rows in bytes
         u32x4 bias[4], wsc[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) bias[ni] = lds_read_b128(bias_r + ni * 64);
         if constexpr (FP8) {
+            const unsigned bias_r = lds_addr(smem + PBIAS) + (seq & 1) * 1024 + (wc * 64 + eq * 4) * 4;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) bias[ni] = lds_read_b128(bias_r + ni * 64);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) wsc[ni] = lds_read_b128(bias_r + (PSCALE - PBIAS) + ni * 64);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wsc[0]), "+v"(wsc[1]), "+v"(wsc[2]), "+v"(wsc[3]) :: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]) :: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]) :: "memory");
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {                 // 8 passes of 16 rows through the wave's private LDS area
+        stamp(8);
+        u32x2 o[4];
+        auto pack = [&](const f32x4 (&a4)[4]) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                f32x4 v = acc[mi][ni];
+                f32x4 v = a4[ni];
                 if constexpr (FP8) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaf(v[r], __uint_as_float(wsc[ni][r]), __uint_as_float(bias[ni][r]));
-                } else {
-                    v[0] += __uint_as_float(bias[ni][0]); v[1] += __uint_as_float(bias[ni][1]);
-                    v[2] += __uint_as_float(bias[ni][2]); v[3] += __uint_as_float(bias[ni][3]);
                 }
                 if constexpr (EPI == EPI_BIAS_QGELU_BF16) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
                 }
-                u32x2 o;
-                o[0] = pack_bf16x2(v[0], v[1]);
-                o[1] = pack_bf16x2(v[2], v[3]);
-                lds_write_b64(epi_w ^ (ni * 32), o);      // chunk (ni*2 + (eq>>1)) ^ (erow & 7): ni only flips bits 5-6
+                o[ni][0] = pack_bf16x2(v[0], v[1]);
+                o[ni][1] = pack_bf16x2(v[2], v[3]);
             }
-            u32x4 d0 = lds_read_b128(epi_r0), d1 = lds_read_b128(epi_r1);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0), "+v"(d1) :: "memory");
-            // Non-temporal stores: C is not read again by this kernel, and written as ordinary write-back lines the 0.1-0.5 GB
-            // of a launch evicts the A / W panels the K loops live on from L2 (measured on the encoder shapes: plain stores
-            // +27 % time on QKV, +17 % on fc1 over no stores at all; `nt` stores +0 % / +6 %; `sc1` write-through +13 %;
-            // the same stores aimed at an L2-resident 8 MiB cost nothing, so the instruction issue is not the price).
-            // Inside the encoder chain (bench.py, same device): all four block GEMMs with plain stores 13 490 items/s,
-            // all non-temporal 14 065; every one of the four contributes, the LayerNorm reading the deltas included.
-            // Inline asm because __builtin_nontemporal_store did not produce this encoding; 2 stores per lane and pass,
-            // the vmcnt bookkeeping in the header counts them.
-            // the timing-experiment flags exist only in the DBG instantiation (tools/: any non-zero flag selects it)
-            if (!DBG || (!(p.dbg & 1) && !((p.dbg & 32) && mi >= 4))) {          // dbg 1 / 32: TIMING ONLY, all / half the stores dropped
-                char* q0 = c_tile + (size_t)(mi * 16) * p.ldc * 2 + c_lane;
-                char* q1 = c_tile + (size_t)(mi * 16 + 8) * p.ldc * 2 + c_lane;
-                if (DBG && (p.dbg & 4))
-                    asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %2, %3, off\n\ts_nop 1"
-                                 :: "v"(q0), "v"(d0), "v"(q1), "v"(d1) : "memory");        // dbg 4: plain stores, for A/B
-                else
-                    asm volatile("global_store_dwordx4 %0, %1, off nt\n\tglobal_store_dwordx4 %2, %3, off nt\n\ts_nop 1"
-                                 :: "v"(q0), "v"(d0), "v"(q1), "v"(d1) : "memory");
+        };
+        u32x4 dA0, dA1, dB0, dB1;           // read-back of the pass in flight in each of the two areas
+        // one pass through LDS: 4 writes of the packed quads, 2 reads of whole 16-byte chunks; area B is 8 KiB behind area A
+#define KEMR_LDS_PASS(D0, D1, OFF, OFF1)                                                                                        \
+        asm volatile("ds_write_b64 %2, %6 offset:" #OFF "\n\tds_write_b64 %3, %7 offset:" #OFF "\n\tds_write_b64 %4, %8 offset:" #OFF "\n\t" \
+                     "ds_write_b64 %5, %9 offset:" #OFF "\n\tds_read_b128 %0, %10 offset:" #OFF "\n\tds_read_b128 %1, %10 offset:" #OFF1 \
+                     : "=&v"(D0), "=&v"(D1)                                                                                     \
+                     : "v"(ew0), "v"(ew1), "v"(ew2), "v"(ew3), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(epi_r) : "memory")
+        // wait for a pass's two reads (WAIT = LDS operations of the next pass issued behind them), then its 2 full-line stores.
+        // Non-temporal: C is not read again by this kernel, and written as ordinary write-back lines the 0.1-0.5 GB of a
+        // launch evicts the A / W panels the K loops live on from L2 (round 1, encoder shapes: plain stores +27 % time on QKV,
+        // +17 % on fc1 over no stores at all; `nt` stores +0 % / +6 %; `sc1` write-through +13 %).  Exactly 16 stores per lane
+        // and tile: the vmcnt bookkeeping in the header counts them.  dbg 1 / 4 (DBG instantiation, tools/): stores dropped / plain.
+#define KEMR_STORE_PASS(D0, D1, WAIT)                                                                                           \
+        do {                                                                                                                    \
+            asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" : "+v"(D0), "+v"(D1) :: "memory");                                      \
+            const unsigned voff8 = voff + step8;                                                                                \
+            if (!DBG || !(p.dbg & 1)) {                                                                                         \
+                if (DBG && (p.dbg & 4))                                                                                         \
+                    asm volatile("global_store_dwordx4 %0, %1, %4\n\tglobal_store_dwordx4 %2, %3, %4\n\ts_nop 1"               \
+                                 :: "v"(voff), "v"(D0), "v"(voff8), "v"(D1), "s"(ctile) : "memory");                            \
+                else                                                                                                            \
+                    asm volatile("global_store_dwordx4 %0, %1, %4 nt\n\tglobal_store_dwordx4 %2, %3, %4 nt\n\ts_nop 1"         \
+                                 :: "v"(voff), "v"(D0), "v"(voff8), "v"(D1), "s"(ctile) : "memory");                            \
+            }                                                                                                                   \
+            voff = voff8 + step8;                                                                                               \
+        } while (0)
+        pack(acc[0]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+        pack(acc[1]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
+        KEMR_STORE_PASS(dA0, dA1, 6); pack(acc[2]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+        KEMR_STORE_PASS(dB0, dB1, 6); pack(acc[3]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
+        KEMR_STORE_PASS(dA0, dA1, 6); pack(acc[4]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+        KEMR_STORE_PASS(dB0, dB1, 6); pack(acc[5]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
+        KEMR_STORE_PASS(dA0, dA1, 6); pack(acc[6]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+        KEMR_STORE_PASS(dB0, dB1, 6); pack(acc[7]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
+        KEMR_STORE_PASS(dA0, dA1, 6);
+        KEMR_STORE_PASS(dB0, dB1, 0);
+#undef KEMR_LDS_PASS
+#undef KEMR_STORE_PASS
+        stamp(9);
+    }
+#undef KEMR_DSR
+#undef KEMR_GLDS
+#undef KEMR_STREAM_STEP1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the streams' pieces behind the last K-tile land in LDS: before the exit
+    if constexpr (DBG) {
+        if (clocking && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 14; ++i) p.stamps[blockIdx.x * 16 + i] = st_slot[i];
+            p.stamps[blockIdx.x * 16 + 14] = (unsigned)ntl;       // tiles of this workgroup
+            p.stamps[blockIdx.x * 16 + 15] = (unsigned)nt;
+            if (!stamping) {
+                unsigned long long clk1, rt1;
+                asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk1), "=s"(rt1) :: "memory");
+                p.stamps[blockIdx.x * 16 + 12] = (unsigned)(clk1 - clk0);
+                p.stamps[blockIdx.x * 16 + 13] = (unsigned)(rt1 - rt0);
             }
         }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();      // pairs with the extra barrier the wr == 1 half took at the start
 }
 
-template <int EPI, bool FP8, bool AFIRST, bool DBG>
-static int launch256u_a(const GemmParams& p, hipStream_t stream) {
-    auto kern = gemm256u_bf16_nt_kernel<EPI, FP8, AFIRST, DBG>;
-    static bool attr_done = false;
-    static int num_cu = 0;
-    if (!attr_done) {
-        KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PSMEM));
-        int dev = 0;
-        KEMR_CHECK_HIP(hipGetDevice(&dev));
+static int gemm256u_num_cu(int* out) {
+    // one process drives one device at a time (torchrun design); re-read when the device changes
+    static int cu_dev = -1, num_cu = 0;
+    int dev = 0;
+    KEMR_CHECK_HIP(hipGetDevice(&dev));
+    if (cu_dev != dev) {
         KEMR_CHECK_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        attr_done = true;
+        cu_dev = dev;
     }
+    *out = num_cu;
+    return KEMR_OK;
+}
+
+// what the kernel's tile table and 32-bit tile offsets can hold (everything the encoders launch is far inside)
+bool gemm256u_fits(const GemmParams& p, int elem_size) {
+    int num_cu = 0;
+    if (gemm256u_num_cu(&num_cu) != KEMR_OK || num_cu <= 0) return false;
+    const long tiles = (long)((p.M + 255) / 256) * (p.N / 256);
+    const long grid = tiles < num_cu ? tiles : num_cu;
+    const long rows = (long)((p.M + 255) / 256) * 256;
+    return (tiles + grid - 1) / grid <= GEMM256U_MAX_TILES_PER_WG && rows * p.lda * elem_size < (1L << 32) &&
+           (long)p.N * p.ldw * elem_size < (1L << 32) && rows * p.ldc * 2 < (1L << 32);
+}
+
+template <int EPI, bool FP8, bool DBG>
+static int launch256u_a(const GemmParams& p, hipStream_t stream) {
+    auto kern = gemm256u_bf16_nt_kernel<EPI, FP8, DBG>;
+    static int attr_dev = -1;
+    int dev = 0, num_cu = 0;
+    KEMR_CHECK_HIP(hipGetDevice(&dev));
+    KEMR_TRY(gemm256u_num_cu(&num_cu));
+    if (attr_dev != dev) {
+        KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PSMEM));
+        attr_dev = dev;
+    }
+    if (!gemm256u_fits(p, FP8 ? 1 : 2)) KEMR_FAIL(KEMR_ERR_INVALID, "gemm256u: M=%d N=%d K=%d is beyond the persistent kernel's tile table / 32-bit tile offsets", p.M, p.N, p.K);
     const int tiles = ((p.M + 255) / 256) * (p.N / 256);
     const int grid = tiles < num_cu ? tiles : num_cu;
     GemmParams q = p;
     q.dbg = g_gemm_dbg;
+    q.order = g_gemm_order;
+    q.stamps = nullptr;
+    if (DBG && (g_gemm_dbg & (64 | 128))) KEMR_CHECK_HIP(hipGetSymbolAddress((void**)&q.stamps, HIP_SYMBOL(g_gemm_stamp_buf)));
     ProfScope prof(PROF_GEMM, stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), PSMEM, stream, q);
     KEMR_CHECK_LAUNCH("gemm256u_bf16_nt_kernel");
@@ -348,9 +660,17 @@ static int launch256u_a(const GemmParams& p, hipStream_t stream) {
 
 template <int EPI, bool FP8>
 static int launch256u(const GemmParams& p, hipStream_t stream) {
-    const int nt = FP8 ? p.K >> 7 : p.K >> 6;
-    if (g_gemm_dbg && !FP8) return nt >= 32 ? launch256u_a<EPI, false, true, true>(p, stream) : launch256u_a<EPI, false, false, true>(p, stream);
-    return nt >= 32 ? launch256u_a<EPI, FP8, true, false>(p, stream) : launch256u_a<EPI, FP8, false, false>(p, stream);
+    if (g_gemm_dbg && !FP8) return launch256u_a<EPI, false, true>(p, stream);
+    return launch256u_a<EPI, FP8, false>(p, stream);
+}
+
+// tools/ only: the stamp sums of the last DBG launch with flag 64 (per workgroup: 8 K-loop intervals, K-loop tail, epilogue,
+// tiles, K-tiles per tile)
+int gemm_read_stamps(unsigned* host_out, int n_words) {
+    if (n_words < 0 || n_words > 1024 * 16) KEMR_FAIL(KEMR_ERR_INVALID, "gemm stamps: at most %d words", 1024 * 16);
+    if (g_gemm_variant == 10) return gemm_read_stamps1(host_out, n_words);      // TEMPORARY A/B: the round-1 kernel's buffer
+    KEMR_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_stamp_buf), (size_t)n_words * 4, 0, hipMemcpyDeviceToHost));
+    return KEMR_OK;
 }
 
 // C must have ceil256(M) rows: rows in [M, ceil256(M)) are written (with values computed from A's pad rows).
