@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: CLIP ViT-L/14 gallery encode (images + texts / s) and Q x 43k similarity + top-10 (ms).
 
-    python bench.py --gpus 1 --steps 8 --warmup 2
+    python bench.py                      # N = 1, the whole 43k gallery: ceil(43000 / 255) = 169 steps, ~9 s timed
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -104,8 +105,8 @@ def gemm_flops_per_step(arch, batch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps; 0 = the whole gallery shard, ceil(43000 / gpus / batch)")
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=255, help="gallery items per rank per step")
     ap.add_argument("--model", default="ViT-L/14")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16-res16", "fp8", "fp8-mlp"],
@@ -114,6 +115,7 @@ def main():
     ap.add_argument("--gemm-variant", type=int, default=0, help="A/B only: force a GEMM tile variant (0 = the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sim", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp8 / bf16-res16 sub-results (two more engines, ~20 steps each)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,6 +139,8 @@ def main():
 
     arch = ARCHS[args.model]
     B = args.batch
+    if args.steps <= 0:
+        args.steps = -(-GALLERY // (world * B))          # every rank encodes its whole contiguous shard of the gallery
     eng = engine.ClipEngine(arch, dev, precision=args.precision)
     if args.image_slice:
         engine.MAX_IMAGE_BATCH = args.image_slice
@@ -175,6 +179,9 @@ def main():
         elapsed = float(t.item())
     assert all(torch.isfinite(o).all().item() for o in out)
 
+    rccl_ranks = dist.get_world_size() if dist is not None else 1
+    per_shard = (GALLERY + world - 1) // world
+    shard_bounds = [[r * per_shard, min(GALLERY, (r + 1) * per_shard)] for r in range(world)]
     items = 3 * B * world * args.steps                       # images + query texts + target texts
     value = items / elapsed
     flops_item_step = B * (arch.image_flops() + 2 * arch.text_flops())
@@ -185,7 +192,9 @@ def main():
         "vs_baseline": None, "dtype": {"fp8": "fp8 (QKV) + bf16", "fp8-mlp": "fp8 (QKV, fc1) + bf16"}.get(args.precision, "bf16"), "data": "synthetic",
         "config": {"workload": "CLIP ViT-L/14 zero-shot: 43k-gallery encode (1 image + query + target text per item, "
                                "224x224 / 77 tokens) + T2I top-10, BASELINE configs[1]",
-                   "model": args.model, "residual_stream": "bf16" if args.precision == "bf16-res16" else "fp32", "batch_per_gpu": B, "gallery": GALLERY, "parallelism": f"dp{world} (gallery sharded)"},
+                   "model": args.model, "residual_stream": "bf16" if args.precision == "bf16-res16" else "fp32", "batch_per_gpu": B, "gallery": GALLERY, "parallelism": f"dp{world} (gallery sharded)",
+                   "items_timed": items, "rccl_ranks": rccl_ranks, "backend": (os.environ.get("KEMR_DIST_BACKEND", "nccl") if world > 1 else None),
+                   "shard_bounds": shard_bounds},
         "images_per_s": B * world * args.steps / elapsed,
         "texts_per_s": 2 * B * world * args.steps / elapsed,
         "encode_tflops_per_gpu": flops_item_step * args.steps / elapsed / 1e12,
@@ -204,16 +213,20 @@ def main():
     gemm_flops, _ = gemm_flops_per_step(arch, B)
     gemm_ms, gemm_n = ms[0] / prof_steps, cnt[0] // prof_steps
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
-    # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the
-    # gfx950 correction, + WRITE_SIZE), committed under profiles/; bench.py cannot collect PMC counters itself.
-    traffic = None
+    # L2-miss (fabric) bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes of this command
+    # (tools/profile_round.sh <tag> pmc: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), committed under
+    # profiles/ with the commit they were measured on; bench.py cannot collect PMC counters itself, and the figure is
+    # attached only to the configuration it was measured for.
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-    if os.path.exists(tpath) and args.model == "ViT-L/14" and B == 255:
+    if os.path.exists(tpath) and args.model == "ViT-L/14" and B == 255 and args.precision == "bf16" and args.gemm_variant == 0:
         with open(tpath) as f:
-            traffic = json.load(f).get("bytes_per_launch")
+            tj = json.load(f)
+        traffic, traffic_source = tj.get("bytes_per_launch"), {k: tj.get(k) for k in ("profile", "round", "commit", "algorithmic_bytes_per_launch")}
     result["roofline"] = {
-        "kernel": "gemm256u_bf16_nt_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
-        "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+        "kernel": "gemm256u_bf16_nt_kernel (all launches of the GEMM class timed by hipEvents on the launch stream: 192 persistent + the patch-embedding GEMM)",
+        "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
+        "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
         "launches_per_step": int(gemm_n), "avg_launch_us": 1e3 * gemm_ms / max(gemm_n, 1),
         "flops_per_launch": gemm_flops / max(gemm_n, 1),
     }
@@ -227,26 +240,45 @@ def main():
         gg = torch.Generator(device=dev).manual_seed(7)
         gal_all = torch.nn.functional.normalize(torch.randn(GALLERY, arch.embed_dim, generator=gg, device=dev), dim=-1)
         qry_all = torch.nn.functional.normalize(gal_all + 0.04 * torch.randn(GALLERY, arch.embed_dim, generator=gg, device=dev), dim=-1)
+        tgt_all = torch.nn.functional.normalize(gal_all + 0.5 * torch.randn(GALLERY, arch.embed_dim, generator=gg, device=dev), dim=-1)
         sim = {}
-        for label, nq, terms in (("q1024_bf16", 1024, 1), ("q43000_bf16", GALLERY, 1), ("q43000_fp32x3", GALLERY, 3)):
-            gp = engine.build_panel([gal_all[lo:hi]], _lib.SIDE_GALLERY, terms)
+        # (label, queries, bf16 terms, parts): parts == 2 is BASELINE configs[2], fused T2I + T2T scoring (0.5 / 0.5) as ONE
+        # contraction over the concatenated weighted panels (reference metrics.py:145-148); k == 0 = ranks only (what the
+        # Recall@K / MRR metrics need)
+        cases = (("q1024_bf16", 1024, 1, 1, 10), ("q43000_bf16", GALLERY, 1, 1, 10), ("q43000_bf16_rank_only", GALLERY, 1, 1, 0),
+                 ("q43000_fp32x3", GALLERY, 3, 1, 10), ("q43000_bf16_c3_fused_t2i_t2t", GALLERY, 1, 2, 10))
+        for label, nq, terms, parts, k in cases:
+            gparts = [gal_all[lo:hi]] + ([tgt_all[lo:hi]] if parts == 2 else [])
+            gp = engine.build_panel(gparts, _lib.SIDE_GALLERY, terms)
             qs = qry_all[:nq]
+            gt = torch.arange(nq, dtype=torch.int32, device=dev)
 
             def run():
-                qp = engine.build_panel([qs], _lib.SIDE_QUERY, terms)   # queries arrive as fp32 embeddings
-                gt = torch.arange(nq, dtype=torch.int32, device=dev)
-                s, i = engine.sim_topk(qp, gp, 10, lo)
+                qp = engine.build_panel([qs] * parts, _lib.SIDE_QUERY, terms, part_scale=[1.0 / parts] * parts)   # queries arrive as fp32 embeddings
+                ahead = None
+                if k == 0:                                             # rank of the diagonal ground truth (shard-local part of it)
+                    inside = (gt >= lo) & (gt < hi)
+                    sgt = engine.pair_scores(qp, gp, gt, (gt - lo).clamp(0, hi - lo - 1))
+                    if dist is not None:                               # the owner shard's score of every query's ground truth
+                        sgt = torch.where(inside, sgt, torch.zeros_like(sgt))
+                        dist.all_reduce(sgt)
+                    ahead = torch.zeros(nq, dtype=torch.int32, device=dev)
+                    engine.sim_topk(qp, gp, 0, lo, gt, sgt, ahead)
+                    if dist is not None:
+                        dist.all_reduce(ahead)
+                    return ahead, None
+                s, i = engine.sim_topk(qp, gp, k, lo)
                 if dist is not None:                                   # exchange step: candidates of every shard, then merge
                     ss = [torch.empty_like(s) for _ in range(world)]
                     ii = [torch.empty_like(i) for _ in range(world)]
                     dist.all_gather(ss, s)
                     dist.all_gather(ii, i)
-                    s, i = engine.topk_merge(torch.stack(ss, 1), torch.stack(ii, 1), 10)
+                    s, i = engine.topk_merge(torch.stack(ss, 1), torch.stack(ii, 1), k)
                 return s, i
 
             run()
             barrier()
-            reps = 5 if nq <= 2048 else 2
+            reps = 5 if nq <= 2048 else 3
             t1 = time.perf_counter()
             for _ in range(reps):
                 s, i = run()
@@ -256,11 +288,52 @@ def main():
                 tt = torch.tensor([dt], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dt = float(tt.item())
-            flops = 2.0 * nq * GALLERY * arch.embed_dim * terms
-            sim[label] = {"ms": 1e3 * dt, "mfma_tflops_per_gpu": flops / dt / 1e12 / world,
-                          "top1_hit": float((i[:, 0].long() == torch.arange(nq, device=dev)).float().mean())}
+            kdim = arch.embed_dim * terms * parts
+            flops = 2.0 * nq * GALLERY * kdim
+            sim[label] = {"ms": 1e3 * dt, "mfma_tflops_per_gpu": flops / dt / 1e12 / world, "kdim": kdim}
+            if k:
+                sim[label]["top1_hit"] = float((i[:, 0].long() == torch.arange(nq, device=dev)).float().mean())
+            else:
+                sim[label]["rank1"] = float((s == 0).float().mean())
             del gp
         result["sim_top10"] = sim
+        # roofline of the similarity kernel at the headline size (MFMA-bound: SURVEY 8(d)); min_bytes = both panels read once +
+        # the lists written
+        hs = sim["q43000_bf16"]
+        result["roofline_sim"] = {"kernel": "sim_kernel + topk_merge (panel build of the queries included)", "bound": "mfma",
+                                  "flops": 2.0 * GALLERY * GALLERY * arch.embed_dim, "ms": hs["ms"],
+                                  "achieved": hs["mfma_tflops_per_gpu"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": hs["mfma_tflops_per_gpu"] / PEAK_BF16_TFLOPS,
+                                  "min_bytes": 2 * GALLERY * arch.embed_dim * 2 + GALLERY * 10 * 8}
+
+    # ------------------------------------------------------------------ sub-results: the same step at other precisions
+    if not args.no_extras and args.precision == "bf16":
+        extras = {}
+        for prec in ("bf16-res16", "fp8"):
+            e2 = engine.ClipEngine(arch, dev, precision=prec)
+            e2.load_state_dict(random_weights(arch, seed=0))
+
+            def step2():
+                return (e2.encode_image(pixels, normalize=True), e2.encode_text(q_ids, normalize=True), e2.encode_text(t_ids, normalize=True))
+
+            for _ in range(3):
+                o2 = step2()
+            barrier()
+            n2 = 20
+            t1 = time.perf_counter()
+            for _ in range(n2):
+                o2 = step2()
+            barrier()
+            dt = time.perf_counter() - t1
+            if dist is not None:
+                tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            cos = [float(torch.nn.functional.cosine_similarity(a.double(), b.double()).min()) for a, b in zip(o2, out)]
+            extras[prec] = {"items_per_s": 3 * B * world * n2 / dt, "ms_per_step": 1e3 * dt / n2, "steps": n2,
+                            "min_cosine_vs_bf16_image_query_target": cos}
+            del e2
+        result["other_precisions"] = extras
 
     # ------------------------------------------------------------------ CPU baseline (oracle, bounded sample)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -268,28 +341,36 @@ def main():
         oa = clip_ref.ARCHS[args.model]
         threads = torch.get_num_threads()
         sd = random_weights(arch, seed=0)
-        n_img, n_txt = 6, 12
-        px = pixels[:n_img].cpu()
-        ids = torch.cat([q_ids[:n_txt // 2], t_ids[:n_txt // 2]]).cpu()
+        # 64+ items of the same synthetic batch in the step's 1 : 2 image : text mix, spread over the batch
+        # (first / middle / last rows, the last one included: token row 65 534 of the 256-row GEMM tiles), and the
+        # reference-style ranking (sgemm + two full argsorts) at N = 8 192
+        n_img, n_txt = 22, 44
+        pick = lambda n, k: torch.unique(torch.cat([torch.arange(0, k // 3), torch.arange(n // 2 - k // 6, n // 2 - k // 6 + k // 3),
+                                                    torch.arange(n - (k - 2 * (k // 3)), n)]))
+        ii, it = pick(B, n_img), pick(B, n_txt // 2)
+        px = pixels[ii].cpu()
+        ids = torch.cat([q_ids[it], t_ids[it]]).cpu()
         clip_ref.encode_text(sd, oa, ids[:2])                       # warm the allocator / thread pool
         t1 = time.perf_counter()
         ci = clip_ref.l2_normalize(clip_ref.encode_image(sd, oa, px))
         ct = clip_ref.l2_normalize(clip_ref.encode_text(sd, oa, ids))
         t_enc = time.perf_counter() - t1
-        # same mix as the GPU step: 1 image : 2 texts
-        t_img, t_txt = None, None
-        cpu_items_per_s = (n_img + n_txt) / t_enc
-        n_rank = 4096
+        cpu_items_per_s = (len(ii) + len(ids)) / t_enc
+        n_rank = 8192
         im, qq, tt_ = metrics_ref.planted_embeddings(n_rank, arch.embed_dim, seed=0)
         t1 = time.perf_counter()
         metrics_ref.retrieval_metrics(qq, im, "T2I")
         t_rank = time.perf_counter() - t1
-        cos = float(torch.nn.functional.cosine_similarity(out[0][:n_img].cpu().double(), ci.double()).min())
+        cosf = lambda a, b: float(torch.nn.functional.cosine_similarity(a.cpu().double(), b.double()).min())
+        cos_img = cosf(out[0][ii], ci)
+        cos_txt = min(cosf(out[1][it], ct[:len(it)]), cosf(out[2][it], ct[len(it):]))
+        assert cos_img > 1 - 1e-3 and cos_txt > 1 - 1e-3, (cos_img, cos_txt)          # north_star parity bar
         result["cpu_baseline"] = {
             "value": cpu_items_per_s, "unit": "items/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/clip_ref fp32 torch on {threads} threads: {n_img} images + {n_txt} texts of the same "
-                      f"synthetic batch ({t_enc:.1f} s); oracle/metrics_ref sgemm + full argsort R@K/MRR at N={n_rank}: {t_rank:.2f} s",
-            "rank_metrics_n4096_s": t_rank, "gpu_vs_oracle_min_cosine_on_sample": cos,
+            "sample": f"oracle/clip_ref fp32 torch on {threads} threads: {len(ii)} images + {len(ids)} texts of the same "
+                      f"synthetic batch, rows from its start, middle and end ({t_enc:.1f} s); oracle/metrics_ref sgemm + full argsort "
+                      f"R@K/MRR at N={n_rank}: {t_rank:.2f} s",
+            "rank_metrics_n8192_s": t_rank, "gpu_vs_oracle_min_cosine_images": cos_img, "gpu_vs_oracle_min_cosine_texts": cos_txt,
         }
 
     if rank == 0:

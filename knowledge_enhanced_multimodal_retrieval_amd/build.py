@@ -18,7 +18,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "libkemr.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "gemm256p.hip", "gemm256q.hip", "gemm256w.hip", "gemm256r.hip", "gemm256u.hip", "gemm256u1.hip", "gemm_skinny.hip", "layernorm.hip", "attention.hip", "embed.hip", "sim.hip", "rank.hip", "preprocess.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "gemm256p.hip", "gemm256q.hip", "gemm256w.hip", "gemm256r.hip", "gemm256u.hip", "gemm_skinny.hip", "layernorm.hip", "attention.hip", "embed.hip", "sim.hip", "rank.hip", "preprocess.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "kemr.h")]
 ARCH = "gfx950"
 

@@ -8,7 +8,9 @@ Weights: upstream ``clip.load(name)`` downloads a checkpoint, which is impossibl
 * ``name`` may be a path to a state-dict file (``.pt`` with ``model_state_dict`` / ``state_dict`` / bare dict,
   loaded with ``weights_only=True``; or ``.safetensors``), optionally ``"ViT-L/14@/path/file"``;
 * or a known model name: ``$KEMR_CLIP_WEIGHTS/<name with / -> ->.pt|.safetensors`` is used when present;
-* otherwise the architecture is built with seeded random weights and a warning says so (synthetic-data runs).
+* otherwise ``load`` raises: a run on random weights looks like any other run in its metrics file.  Synthetic-data runs
+  opt in explicitly with ``allow_random_weights()`` (what ``--synthetic`` does) or ``KEMR_ALLOW_RANDOM_WEIGHTS=1``; the
+  model then records ``weights_source = "random(seed 0)"``, which the evaluators write into their results JSON.
 """
 from __future__ import annotations
 
@@ -24,6 +26,17 @@ from .preprocess import ClipPreprocess
 from .tokenizer import tokenize  # noqa: F401  (re-exported)
 
 _PUBLIC = ("ViT-B/32", "ViT-B/16", "ViT-L/14")
+_allow_random = False
+
+
+def allow_random_weights(flag: bool = True) -> None:
+    """Opt in to seeded random weights when no checkpoint is available (synthetic-data runs, tests)."""
+    global _allow_random
+    _allow_random = bool(flag)
+
+
+def random_weights_allowed() -> bool:
+    return _allow_random or os.environ.get("KEMR_ALLOW_RANDOM_WEIGHTS", "") == "1"
 
 
 def available_models() -> List[str]:
@@ -64,7 +77,14 @@ def load(name: str, device: Union[str, torch.device] = "cuda" if torch.cuda.is_a
         raise RuntimeError("pass a checkpoint as '<model name>@<path>' so that the architecture is known")
     if name not in ARCHS:
         raise RuntimeError(f"Model {name} not found; available models = {available_models()}")
+    if path and not os.path.isfile(path):
+        raise FileNotFoundError(f"clip.load: checkpoint {path!r} does not exist")
     path = path or _weights_for(name)
+    if not path and not random_weights_allowed():
+        raise FileNotFoundError(
+            f"clip.load({name!r}): no checkpoint available offline.  Set KEMR_CLIP_WEIGHTS=<dir with {name.replace('/', '-')}.pt|.safetensors>, "
+            f"pass '{name}@/path/to/state_dict.pt', or opt in to seeded RANDOM weights (synthetic-data runs: --synthetic, "
+            "clip_api.allow_random_weights(), KEMR_ALLOW_RANDOM_WEIGHTS=1)")
     seed_state = torch.random.get_rng_state()
     torch.manual_seed(0)                     # reproducible random init when no weights are available
     try:
@@ -73,8 +93,9 @@ def load(name: str, device: Union[str, torch.device] = "cuda" if torch.cuda.is_a
         torch.random.set_rng_state(seed_state)
     if path:
         model.load_state_dict(read_state_dict(path), strict=True)
+        model.weights_source = os.path.abspath(path)
     else:
-        warnings.warn(f"clip.load({name!r}): no checkpoint available offline (set KEMR_CLIP_WEIGHTS or pass "
-                      f"'{name}@/path/to/state_dict.pt'); using seeded RANDOM weights", RuntimeWarning, stacklevel=2)
+        warnings.warn(f"clip.load({name!r}): seeded RANDOM weights (explicitly allowed)", RuntimeWarning, stacklevel=2)
+        model.weights_source = "random(seed 0)"
     model = model.to(device).eval()
     return model, ClipPreprocess(get_arch(name).image_size)

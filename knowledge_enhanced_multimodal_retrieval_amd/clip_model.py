@@ -27,9 +27,21 @@ def _unwrap(model: nn.Module) -> nn.Module:
 def load_clip_model(model_name: str = "ViT-L/14", checkpoint_path: Optional[str] = None,
                     device: str = "cuda:0") -> Tuple[nn.Module, object]:
     logger.info(f"Loading CLIP model: {model_name}")
-    clip_model, preprocess = clip_api.load(model_name, device=device)
+    # the reference reads a missing path as "no checkpoint" (clip_model.py:47) and still has pretrained weights underneath;
+    # here that would silently evaluate whatever clip.load() found, so a path that is given must exist
+    if checkpoint_path and not Path(checkpoint_path).exists():
+        raise FileNotFoundError(f"load_clip_model: checkpoint {checkpoint_path!r} does not exist")
+    if checkpoint_path and not clip_api.random_weights_allowed() and not clip_api._weights_for(model_name):
+        # the fine-tuned checkpoint replaces every tensor (strict load): the base weights underneath do not matter
+        clip_api.allow_random_weights(True)
+        try:
+            clip_model, preprocess = clip_api.load(model_name, device=device)
+        finally:
+            clip_api.allow_random_weights(False)
+    else:
+        clip_model, preprocess = clip_api.load(model_name, device=device)
     clip_model = clip_model.float()
-    if checkpoint_path and Path(checkpoint_path).exists():
+    if checkpoint_path:
         print(f"Loading checkpoint from {checkpoint_path}")
         checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
         if "model_state_dict" in checkpoint:
@@ -42,6 +54,7 @@ def load_clip_model(model_name: str = "ViT-L/14", checkpoint_path: Optional[str]
             state_dict = checkpoint
             print("  Loaded checkpoint as state_dict directly")
         clip_model.load_state_dict(state_dict, strict=True)
+        clip_model.weights_source = str(Path(checkpoint_path).resolve())
         logger.info("Checkpoint loaded successfully")
         if "epoch" in checkpoint:
             logger.info(f"  Checkpoint epoch: {checkpoint['epoch']}")

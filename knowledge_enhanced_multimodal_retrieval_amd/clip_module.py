@@ -77,6 +77,7 @@ class CLIP(nn.Module):
         self.text_projection = nn.Parameter(torch.empty(arch.t_width, arch.embed_dim))
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
         self._engine: Optional[ClipEngine] = None
+        self._packed_fp = None
         self._dirty = True
         self.initialize_parameters()
 
@@ -112,8 +113,30 @@ class CLIP(nn.Module):
         return out
 
     def refresh(self) -> None:
-        """Re-pack the current parameter values into the HIP engine (call after in-place weight edits)."""
+        """Re-pack the current parameter values into the HIP engine (forces what `engine()` detects by itself)."""
         self._dirty = True
+
+    def _fingerprint(self):
+        """Cheap identity of the parameter values: in-place edits (optimizer.step(), p.data.copy_(), p.add_()) bump a
+        tensor's version counter, re-assignment changes its storage.  The reference's trainer validates through
+        `evaluate_clip_model_for_training` right after optimizer.step() (train/trainer.py:241)."""
+        return tuple((p._version, p.data_ptr()) for p in self.parameters())
+
+    def __deepcopy__(self, memo):
+        """The packed engine is a raw library handle: a copy gets its own, built lazily (never two owners of one handle)."""
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k in ("_engine", "_packed_fp") else copy.deepcopy(v, memo)
+        new._dirty = True
+        return new
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_engine"], state["_packed_fp"], state["_dirty"] = None, None, True
+        return state
 
     def engine(self) -> ClipEngine:
         dev = self.visual.proj.device
@@ -124,9 +147,10 @@ class CLIP(nn.Module):
             # encoder precision of the packed copy: "bf16" unless KEMR_PRECISION says otherwise (bf16-res16 | fp8 | fp8-mlp,
             # kemr_precision in include/kemr.h) -- an environment switch so that the reference's scripts stay unchanged
             self._engine, self._dirty = ClipEngine(self.arch, dev, precision=os.environ.get("KEMR_PRECISION", "bf16")), True
-        if self._dirty:
+        fp = self._fingerprint()
+        if self._dirty or fp != getattr(self, "_packed_fp", None):
             self._engine.load_state_dict({k: v for k, v in self.state_dict().items() if k != "logit_scale"})
-            self._dirty = False
+            self._dirty, self._packed_fp = False, fp
         return self._engine
 
     # ------------------------------------------------------------------ the duck-typed API

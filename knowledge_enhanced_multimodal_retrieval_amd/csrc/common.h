@@ -113,14 +113,12 @@ struct GemmParams {
 extern int g_gemm_dbg;
 extern int g_gemm_order;
 int gemm_read_stamps(unsigned* host_out, int n_words);
-int gemm_read_stamps1(unsigned* host_out, int n_words);
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);      // picks the tile variant
 int launch_gemm256(const GemmParams& p, int epi, hipStream_t stream);   // gemm256.hip: 256x256x64, 8 waves, counted vmcnt
 int launch_gemm256p(const GemmParams& p, int epi, hipStream_t stream);  // gemm256p.hip: persistent, async epilogue (bf16-store epilogues)
 int launch_gemm256q(const GemmParams& p, int epi, hipStream_t stream);  // gemm256q.hip: persistent, 2 long phases per K-tile
 int launch_gemm256u(const GemmParams& p, int epi, hipStream_t stream);  // gemm256u.hip: gemm256p's K loop, one K-tile pipeline across tiles
 bool gemm256u_fits(const GemmParams& p, int elem_size);               // gemm256u.hip: inside its tile table / 32-bit offsets
-int launch_gemm256u1(const GemmParams& p, int epi, hipStream_t stream); // TEMPORARY A/B: the round-1 kernel
 int launch_gemm256u_fp8(const GemmParams& p, int epi, hipStream_t stream);  // gemm256u.hip: fp8 e4m3 operands (A, W in bytes), bf16 C
 int launch_gemm256r(const GemmParams& p, int epi, hipStream_t stream);  // gemm256r.hip: persistent, 4 waves x 128x128, register-staged operands
 int launch_gemm_skinny(const GemmParams& p, int epi, hipStream_t stream);   // gemm_skinny.hip: M <= 512 rows (online queries), split-K over 8 waves

@@ -168,7 +168,7 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
 
 int g_gemm_variant = 0;
 int g_gemm_dbg = 0;
-int g_gemm_order = 0;
+int g_gemm_order = 3;      // gemm256u tile order: column groups of 4 tiles (tools/bench_gemm_r2.py: fc1 -1 %, QKV -0.4 % against N fastest)
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     if (p.M <= 0) return KEMR_OK;
@@ -182,7 +182,6 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     const bool bf16_epi = epi == EPI_BIAS_BF16 || epi == EPI_BIAS_QGELU_BF16;
     // a handful of rows (one or a few online queries): 6-24 tiles would leave the chip idle; split K inside the workgroup
     if (bf16_epi && p.c_rows_padded && (g_gemm_variant == 8 || (g_gemm_variant == 0 && p.M <= 512))) return launch_gemm_skinny(p, epi, stream);
-    if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 10) return launch_gemm256u1(p, epi, stream);
     if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 5) return launch_gemm256q(p, epi, stream);
     if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 6) return launch_gemm256w(p, epi, stream);
     if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 9) return launch_gemm256r(p, epi, stream);

@@ -203,9 +203,16 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
 
     // staging addresses = wave-uniform K-tile pointer (SGPRs) + a per-lane 32-bit byte offset that never changes
     const int srow = lane >> 3, schunk = lane & 7;
-    const int r0 = wid * 16 + srow, r1 = r0 + 8;
-    const unsigned a_lane0 = (unsigned)(r0 * p.lda * ES + ((schunk ^ ((r0 >> 1) & 7)) << 4));
-    const unsigned a_lane1 = (unsigned)(r1 * p.lda * ES + ((schunk ^ ((r1 >> 1) & 7)) << 4));
+    const int r0 = wid * 16 + srow, r1 = r0 + 8;                    // W: every wave stages 16 rows of each 128-row half
+    // A: a wave half stages ITS OWN 128-row region (the only one it reads), 32 rows per wave in four 8-row pieces, so that the
+    // wait for the A pieces only has to be agreed inside the half (see the K-tile schedule below)
+    const int ar = wr * 128 + (wid & 3) * 32 + srow;
+    unsigned a_lane[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = ar + j * 8;
+        a_lane[j] = (unsigned)(r * p.lda * ES + ((schunk ^ ((r >> 1) & 7)) << 4));
+    }
     const unsigned w_lane0 = (unsigned)(r0 * p.ldw * ES + ((schunk ^ ((r0 >> 1) & 7)) << 4));
     const unsigned w_lane1 = (unsigned)(r1 * p.ldw * ES + ((schunk ^ ((r1 >> 1) & 7)) << 4));
 
@@ -215,8 +222,8 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     // seq* = the tile's position in the table.
     int tw = nt, seqw = 0, ta = nt, seqa = 0;
     unsigned ow = __builtin_amdgcn_readlane(v_woff, 0), oa = __builtin_amdgcn_readlane(v_aoff, 0);
-    const unsigned a_half = 128u * (unsigned)(p.lda * ES), w_half = 128u * (unsigned)(p.ldw * ES);     // bytes between the two half-tiles
-    unsigned ow1 = ow + w_half, oa1 = oa + a_half;
+    const unsigned w_half = 128u * (unsigned)(p.ldw * ES);     // bytes between the two W half-tiles
+    unsigned ow1 = ow + w_half;
     // one advance, branch-free, in five steps (inside the K loop one step per MFMA gap, see the hooks):
     //   1 --t; wrapped = t == 0; t = wrapped ? nt : t; seq += wrapped     (SCC carries `wrapped` into the s_addc)
     //   2 tile offset of table entry seq   3 offset + 128   4 pick by t == nt (true only right after a wrap)   5 second half
@@ -235,18 +242,19 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
         toff_a = __builtin_amdgcn_readlane(v_aoff, seqa);
         inc_a = oa + 128;
         oa = ta == nt ? toff_a : inc_a;
-        oa1 = oa + a_half;
     };
     // LDS-DMA of one 16-row x 128-byte piece per wave: SGPR matrix base + per-lane 32-bit offset -> LDS at M0 + lane * 16.
     // All LDS-DMA of the kernel goes through this statement (M0 is written in the statement that uses it; the compiler has no
     // LDS-DMA of its own here whose M0 it could move across).
 #define KEMR_GLDS(VOFF, SBASE, LDSADDR) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" \
                                                      :: "v"(VOFF), "s"(SBASE), "s"(LDSADDR) : "memory")
-    const unsigned stage_lds = lds_addr(smem) + wid * 2048;
-    auto stage_a = [&](unsigned off, unsigned dst) {
-        const unsigned v0 = a_lane0 + off, v1 = a_lane1 + off;
-        KEMR_GLDS(v0, p.A, dst);
-        KEMR_GLDS(v1, p.A, dst + 1024);
+    const unsigned stage_lds = lds_addr(smem) + wid * 2048;        // W pieces: + region; A pieces use a_dst from the buffer base
+    const unsigned buf_lds = lds_addr(smem);
+    const unsigned a_dst = (unsigned)(wr * PHALF + (wid & 3) * 4096);      // the wave's 32 rows inside its half's region
+    auto stage_a = [&](int pair, unsigned off, unsigned buf) {             // pair 0 / 1: rows 0-15 / 16-31 of the wave's 32
+        const unsigned v0 = a_lane[2 * pair] + off, v1 = a_lane[2 * pair + 1] + off;
+        KEMR_GLDS(v0, p.A, buf + a_dst + pair * 2048);
+        KEMR_GLDS(v1, p.A, buf + a_dst + pair * 2048 + 1024);
     };
     auto stage_w = [&](unsigned off, unsigned dst) {
         const unsigned v0 = w_lane0 + off, v1 = w_lane1 + off;
@@ -278,8 +286,8 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     stage_w(ow, stage_lds + 2 * PHALF);
     stage_w(ow1, stage_lds + 3 * PHALF);
     stage_bias();
-    stage_a(oa, stage_lds);
-    stage_a(oa1, stage_lds + PHALF);
+    stage_a(0, oa, buf_lds);
+    stage_a(1, oa, buf_lds);
     advance_w();                               // W stream -> K-tile 1
     advance_a();                               // A stream -> K-tile 1
     stage_w(ow, stage_lds + PBUF + 2 * PHALF);
@@ -367,7 +375,6 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
         if constexpr (J == 1) { asm volatile("" : "+s"(seqa)); toff_a = __builtin_amdgcn_readlane(v_aoff, seqa); asm volatile("" : "+s"(toff_a)); }
         if constexpr (J == 2) { asm volatile("" : "+s"(oa)); inc_a = oa + 128; asm volatile("" : "+s"(inc_a)); }
         if constexpr (J == 3) { asm volatile("" : "+s"(inc_a)); oa = ta == nt ? toff_a : inc_a; asm volatile("" : "+s"(oa)); }
-        if constexpr (J == 4) { asm volatile("" : "+s"(oa)); oa1 = oa + a_half; asm volatile("" : "+s"(oa1)); }
     };
     auto step_w = [&](auto at) {
         constexpr int J = decltype(at)::value;
@@ -420,13 +427,13 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     auto ktile = [&](auto first_c) {
         constexpr bool FIRST = decltype(first_c)::value;
         const unsigned buf_this = stage_lds + gpar * PBUF;
-        const unsigned buf_next = stage_lds + (gpar ^ 1) * PBUF;
+        const unsigned abuf_next = buf_lds + (gpar ^ 1) * PBUF;
         if constexpr (FP8) {
             const char* sa = smem + gpar * PBUF + a_off;
             const char* sb = smem + gpar * PBUF + b_off;
             ld_w8(w08, sb);
             ld_a8(sa);
-            stage_a(oa, buf_next);
+            stage_a(0, oa, abuf_next);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w08[0]), "+v"(w08[1]), "+v"(af8[0]), "+v"(af8[1]), "+v"(af8[2]), "+v"(af8[3]) :: "memory");
             __builtin_amdgcn_s_barrier();
             stamp(0);
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             __builtin_amdgcn_s_barrier();
             stamp(1);
             ld_w8(w18, sb + 4096);
-            stage_a(oa1, buf_next + PHALF);
+            stage_a(1, oa, abuf_next);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w18[0]), "+v"(w18[1]) :: "memory");     // the reads are done in front of the barrier: W may be re-staged behind the next one
             __builtin_amdgcn_s_barrier();
             stamp(2);
@@ -447,10 +454,11 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             __builtin_amdgcn_s_barrier();
             stamp(4);
             quad8<1, 1, FIRST>(acc, af8, w18, one, nohook);
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // K-tile g+1 landed (everything older too, a tile's stores included)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // W(g+1) landed (and everything older: a tile's stores); all waves agree on it at this barrier
             __builtin_amdgcn_s_barrier();
             stamp(5);
             stage_w(ow1, buf_this + 3 * PHALF);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // the half's own A(g+1) pieces landed; W(g+2) stays in flight
             stage_bias();
             __builtin_amdgcn_s_barrier();
             stamp(6);
@@ -458,7 +466,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             __builtin_amdgcn_s_barrier();
             stamp(7);
         } else {
-            stage_a(oa, buf_next);
+            stage_a(0, oa, abuf_next);
             stamp_pre(10);
             __builtin_amdgcn_s_barrier();
             stamp(0);
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             stamp_pre(11);
             __builtin_amdgcn_s_barrier();
             stamp(1);
-            stage_a(oa1, buf_next + PHALF);
+            stage_a(1, oa, abuf_next);
             __builtin_amdgcn_s_barrier();
             stamp(2);
             cluster<0, false>(acc, ak1, wk1, b4, hook_m2);
@@ -476,12 +484,13 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             __builtin_amdgcn_s_barrier();
             stamp(4);
             cluster<1, FIRST>(acc, ak0, wk0, b4, hook_m3);
-            stamp_pre(12);
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // K-tile g+1 landed (everything older too, a tile's stores included)
-            stamp_pre(13);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // W(g+1) landed (and everything older: a tile's stores); all waves agree on it at this barrier
             __builtin_amdgcn_s_barrier();
             stamp(5);
             stage_w(ow1, buf_this + 3 * PHALF);
+            stamp_pre(12);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // the half's own A(g+1) pieces landed; W(g+2) stays in flight
+            stamp_pre(13);
             stage_bias();
             __builtin_amdgcn_s_barrier();
             stamp(6);
@@ -668,7 +677,6 @@ static int launch256u(const GemmParams& p, hipStream_t stream) {
 // tiles, K-tiles per tile)
 int gemm_read_stamps(unsigned* host_out, int n_words) {
     if (n_words < 0 || n_words > 1024 * 16) KEMR_FAIL(KEMR_ERR_INVALID, "gemm stamps: at most %d words", 1024 * 16);
-    if (g_gemm_variant == 10) return gemm_read_stamps1(host_out, n_words);      // TEMPORARY A/B: the round-1 kernel's buffer
     KEMR_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_stamp_buf), (size_t)n_words * 4, 0, hipMemcpyDeviceToHost));
     return KEMR_OK;
 }

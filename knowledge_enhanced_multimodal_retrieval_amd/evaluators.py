@@ -202,7 +202,11 @@ def _run(args, baseline: bool, log_name: str):
     if not torch.cuda.is_available():
         raise RuntimeError("no GPU visible: the encoders and the ranking run only in the HIP kernels (no CPU fallback)")
     device = args.device if args.device.startswith("cuda") else "cuda"
+    from . import clip_api, tokenizer
     from .clip_model import load_clip_model
+    if args.synthetic > 0:           # synthetic data: seeded random weights / hash token ids are acceptable, and recorded below
+        clip_api.allow_random_weights(True)
+        tokenizer.allow_hash_tokenizer(True)
     model, preprocess = load_clip_model(model_name=args.model_name, checkpoint_path=args.checkpoint, device=device)
     if args.synthetic > 0:
         dataset = SyntheticRetrievalDataset(args.synthetic, model.arch.image_size, args.seed)
@@ -222,7 +226,10 @@ def _run(args, baseline: bool, log_name: str):
     for name, value in sorted(metrics.items()):
         log.info(f"{name}: {value:.2f}" + ("" if "Mean_Rank" in name else "%"))
     results = {"model_name": args.model_name, "checkpoint": args.checkpoint, "split": args.split,
-               "num_samples": len(dataset), "seed": args.seed, "metrics": metrics}
+               "num_samples": len(dataset), "seed": args.seed, "metrics": metrics,
+               # provenance (not in the reference's file): what the numbers were computed with
+               "weights_source": getattr(model, "weights_source", "unknown"), "tokenizer": tokenizer.tokenizer_name(),
+               "precision": os.environ.get("KEMR_PRECISION", "bf16"), "data": "synthetic" if args.synthetic > 0 else args.dataset}
     if not baseline:
         results["tasks"] = list(args.tasks)
     save_metrics_to_json(results, args.output_file)
@@ -280,8 +287,12 @@ def main_fusion(argv=None):
     parser.add_argument("--dataset", type=str, default="xuemduan/reevaluate-image-text-pairs")
     args = parser.parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s")
+    from . import clip_api, tokenizer
     from .clip_model import load_clip_model
     from .fusion_model import FusionModel
+    if args.synthetic > 0:
+        clip_api.allow_random_weights(True)
+        tokenizer.allow_hash_tokenizer(True)
     clip_model, preprocess = load_clip_model(model_name=args.model_name, checkpoint_path=args.clip_checkpoint, device=args.device)
     embed_dim = 768 if "L/14" in args.model_name else 512
     fusion_model = FusionModel(clip_model=clip_model, fusion_type=args.fusion_type, embed_dim=embed_dim).to(args.device)
@@ -297,7 +308,9 @@ def main_fusion(argv=None):
     result = evaluate_fusion_model(fusion_model, dataset, args.batch_size, args.device)
     results = {"model_name": args.model_name, "clip_checkpoint": args.clip_checkpoint,
                "fusion_checkpoint": args.fusion_checkpoint, "fusion_type": args.fusion_type, "split": args.split,
-               "num_samples": len(dataset), "metrics": result}
+               "num_samples": len(dataset), "metrics": result,
+               "weights_source": getattr(clip_model, "weights_source", "unknown"), "tokenizer": tokenizer.tokenizer_name(),
+               "precision": os.environ.get("KEMR_PRECISION", "bf16"), "data": "synthetic" if args.synthetic > 0 else args.dataset}
     if args.output_file:
         Path(args.output_file).parent.mkdir(parents=True, exist_ok=True)
         with open(args.output_file, "w") as f:

@@ -71,6 +71,7 @@ class BPETokenizer:
     """Byte-level BPE with the 49 408-entry CLIP vocabulary (256 bytes, 256 end-of-word bytes, merges, 2 specials)."""
 
     def __init__(self, bpe_path: str):
+        self.path = bpe_path
         self.byte_encoder = bytes_to_unicode()
         merges = gzip.open(bpe_path).read().decode("utf-8").split("\n")
         merges = [tuple(m.split()) for m in merges[1:49152 - 256 - 2 + 1]]
@@ -137,19 +138,42 @@ class HashTokenizer:
 
 
 _tokenizer = None
+_allow_hash = False
+
+
+def allow_hash_tokenizer(flag: bool = True) -> None:
+    """Opt in to the hash tokenizer when the BPE vocabulary is absent (synthetic-data runs, tests)."""
+    global _allow_hash
+    _allow_hash = bool(flag)
+
+
+def hash_tokenizer_allowed() -> bool:
+    return _allow_hash or os.environ.get("KEMR_ALLOW_HASH_TOKENIZER", "") == "1"
 
 
 def get_tokenizer():
+    """The BPE tokenizer when its vocabulary file is found; without it: an error, unless the hash tokenizer was allowed
+    explicitly (its ids are not OpenAI's: text embeddings of a pretrained model would be meaningless)."""
     global _tokenizer
-    if _tokenizer is None:
+    if _tokenizer is None or (isinstance(_tokenizer, HashTokenizer) and not hash_tokenizer_allowed()):
         path = find_vocab()
         if path:
             _tokenizer = BPETokenizer(path)
-        else:
-            warnings.warn("CLIP BPE vocabulary not found (%s): using the deterministic hash tokenizer; token ids are not "
-                          "OpenAI's" % ", ".join(_vocab_candidates()), RuntimeWarning, stacklevel=2)
+        elif hash_tokenizer_allowed():
+            warnings.warn("CLIP BPE vocabulary not found (%s): using the deterministic hash tokenizer (explicitly allowed); "
+                          "token ids are not OpenAI's" % ", ".join(_vocab_candidates()), RuntimeWarning, stacklevel=2)
             _tokenizer = HashTokenizer()
+        else:
+            raise FileNotFoundError(
+                "CLIP BPE vocabulary not found (%s).  Put bpe_simple_vocab_16e6.txt.gz there, or opt in to the hash tokenizer "
+                "(synthetic-data runs: --synthetic, tokenizer.allow_hash_tokenizer(), KEMR_ALLOW_HASH_TOKENIZER=1)"
+                % ", ".join(_vocab_candidates()))
     return _tokenizer
+
+
+def tokenizer_name() -> str:
+    t = get_tokenizer()
+    return "bpe(%s)" % t.path if isinstance(t, BPETokenizer) else "hash (NOT OpenAI ids)"
 
 
 def tokenize(texts: Union[str, Sequence[str]], context_length: int = CONTEXT, truncate: bool = False) -> torch.Tensor:

@@ -7,6 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the tests run on seeded random weights and synthetic text: the two explicit opt-ins of the product path
+# (clip_api.load / tokenizer.get_tokenizer refuse to fall back silently; tests/test_host_logic.py checks that they do)
+os.environ.setdefault("KEMR_ALLOW_RANDOM_WEIGHTS", "1")
+os.environ.setdefault("KEMR_ALLOW_HASH_TOKENIZER", "1")
 
 
 def pytest_configure(config):

@@ -156,6 +156,11 @@ def main():
         ot = clip_ref.encode_text(sd, arch, ids)
         print(name, "oracle vs HF:", float((oi - hi).abs().max()), float((ot - ht).abs().max()))
 
+    # ------------------------------------------------------------------ 4b. the same cross-check at the FULL ViT-L/14 and ViT-B/32
+    # shapes (width / depth / heads / patch of the models the bench and the reference scripts use).  Inputs and weights come
+    # from seeds, so the fixture holds only the HF outputs and checksums of what was fed in (a few KB).
+    hf_full_shape()
+
     # ------------------------------------------------------------------ 5. RetrievalEngine linear fuse (retrieval.py:23-76 is
     # not importable: it needs dotenv + network-bound constructors; the vector below restates its documented arithmetic on a
     # hand-checkable case and is marked "restated", not "reference-generated")
@@ -170,5 +175,38 @@ def main():
     print("done")
 
 
+def hf_full_shape():
+    from transformers import CLIPConfig, CLIPModel
+    from oracle import clip_ref
+    for name in ("ViT-B/32", "ViT-L/14"):
+        arch = clip_ref.ARCHS[name]
+        sd = clip_ref.random_state_dict(arch, seed=0)
+        cfg = CLIPConfig(**clip_ref.hf_config_kwargs(arch))
+        cfg._attn_implementation = "eager"
+        m = CLIPModel(cfg).eval().float()
+        m.load_state_dict(clip_ref.to_hf_state_dict(sd, arch), strict=True)
+        gg = torch.Generator().manual_seed(1234)
+        px = torch.randn(2, 3, arch["image_size"], arch["image_size"], generator=gg)
+        ids = clip_ref.synthetic_ids(arch, 3)
+        with torch.no_grad():
+            hi = m.get_image_features(pixel_values=px)
+            hi = hi if torch.is_tensor(hi) else hi.pooler_output
+            ht = m.get_text_features(input_ids=ids.long())
+            ht = ht if torch.is_tensor(ht) else ht.pooler_output
+        chk = {k: float(v.double().abs().sum()) for k, v in sd.items()}
+        meta = {"pixel_seed": 1234, "pixel_abs_sum": float(px.double().abs().sum()), "n_images": 2, "n_texts": 3,
+                "weight_abs_sums": chk}
+        np.savez_compressed(os.path.join(HERE, "clip_hf_full_%s.npz" % name.replace("/", "-")), ids=ids.numpy(),
+                            image_features=hi.numpy(), text_features=ht.numpy(),
+                            meta_json=np.frombuffer(json.dumps(meta, sort_keys=True).encode(), dtype=np.uint8))
+        oi = clip_ref.encode_image(sd, arch, px)
+        ot = clip_ref.encode_text(sd, arch, ids)
+        print(name, "full shape, oracle vs HF:", float((oi - hi).abs().max()), float((ot - ht).abs().max()), flush=True)
+        del m
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "hf-full":
+        hf_full_shape()
+    else:
+        main()

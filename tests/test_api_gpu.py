@@ -101,6 +101,73 @@ def test_config2_fused_scoring_cli(device, tmp_path):
     assert json.loads(out.read_text())["checkpoint"] == str(ck)
 
 
+@pytest.mark.parametrize("ft", ["gated", "linear", "cross_attention"])
+def test_evaluate_fusion_model_end_to_end(device, tmp_path, ft):
+    """SURVEY 8 row a13 (reference eval/evaluator_fusion.py:28-144, main :147-235): encode -> fused scoring under a learned
+    head -> Recall@K / MRR, through the drop-in module path and its CLI, on synthetic data.  The metrics must equal what the
+    head's own dense score matrix gives under the reference's ranking rule (the reference fills that matrix in 50 x 500
+    blocks; here it never exists for the gated family)."""
+    from src.clip.eval import evaluator_fusion as EF
+    from knowledge_enhanced_multimodal_retrieval_amd import ranking
+    from knowledge_enhanced_multimodal_retrieval_amd.datasets import SyntheticRetrievalDataset
+    from knowledge_enhanced_multimodal_retrieval_amd.evaluators import encode_dataset
+    out = tmp_path / f"fusion_{ft}.json"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = EF.main(["--model_name", "ViT-B/32", "--fusion_type", ft, "--batch_size", "32", "--device", "cuda",
+                       "--synthetic", "80", "--output_file", str(out)])
+    saved = json.loads(out.read_text())
+    assert saved["fusion_type"] == ft and saved["num_samples"] == 80 and saved["weights_source"].startswith("random")
+    assert set(res["metrics"]) == {"R@1", "R@5", "R@10", "R@20", "MRR", "Mean_Rank"}
+    # the same numbers from the dense matrix of the same head (seeded construction: rebuild model and head identically)
+    from knowledge_enhanced_multimodal_retrieval_amd import clip_model
+    from src.clip.models import FusionModel
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cm, _ = clip_model.load_clip_model("ViT-B/32", None, "cuda")
+    fm = FusionModel(clip_model=cm, fusion_type=ft, embed_dim=512).to("cuda").eval()
+    ds = SyntheticRetrievalDataset(80, cm.arch.image_size)
+    res2 = EF.evaluate_fusion_model(fm, ds, 32, "cuda")
+    image, query, target, _ = encode_dataset(cm, ds, 32, 42, 0, None)
+    S = fm(query, image, target).double().cpu().numpy()
+    want = metrics_ref.retrieval_metrics_from_similarity(S)
+    d = np.abs(S - np.diag(S)[:, None])
+    np.fill_diagonal(d, np.inf)
+    if d.min() > 1e-5:                       # no near-tie between a ground truth and another candidate: ranks are unambiguous
+        for key in ("R@1", "R@5", "R@10", "R@20", "MRR", "Mean_Rank"):
+            assert res2[key] == pytest.approx(want[key], abs=1e-9), key
+    assert 1.0 <= res2["Mean_Rank"] <= 80.0
+
+
+def test_module_repacks_after_in_place_weight_edits_and_refuses_nan(device):
+    """(a) the packed engine copy follows in-place parameter edits (optimizer.step(), p.data.copy_) without a manual
+    refresh(), and a deepcopy never shares the raw library handle; (b) non-finite scores are refused instead of ranking first."""
+    import copy
+    from knowledge_enhanced_multimodal_retrieval_amd import clip_api, ranking
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model, _ = clip_api.load("ViT-B/32", device="cuda")
+    px = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(0)).cuda()
+    a = model.encode_image(px).clone()
+    with torch.no_grad():
+        model.visual.proj.mul_(2.0)                      # what an optimizer step does: in place, same storage
+    b = model.encode_image(px)
+    assert torch.allclose(b, 2.0 * a, rtol=2e-2, atol=1e-3) and not torch.allclose(b, a)
+    twin = copy.deepcopy(model)
+    assert twin._engine is None
+    assert torch.equal(twin.encode_image(px), b) and twin._engine is not model._engine
+    # NaN guard
+    q = torch.nn.functional.normalize(torch.randn(8, 64), dim=-1)
+    g = torch.nn.functional.normalize(torch.randn(20, 64), dim=-1)
+    ranking.ranks_and_topk([q], [g], k=3)                # finite: fine
+    q[2, 5] = float("nan")
+    with pytest.raises(ValueError, match="non-finite"):
+        ranking.ranks_and_topk([q], [g], k=3)
+    S = (q @ g.t()).numpy()
+    with pytest.raises(ValueError, match="non-finite"):
+        ranking.ranks_of_matrix(S)
+
+
 @pytest.mark.parametrize("ft", ["linear", "gated", "simple_gated", "simple_gated_with_bias", "bilinear", "cross_attention"])
 def test_fusion_heads_match_reference_golden(device, golden_dir, ft):
     from src.clip.models import FusionModel

@@ -20,8 +20,8 @@ def test_bench_cli_declares_the_contract_flags():
 
 @pytest.mark.gpu
 def test_bench_line_contract(device):
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"], capture_output=True,
-                         text=True, timeout=600, cwd=ROOT)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-extras"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     line = res.stdout.strip().splitlines()[-1]
     d = json.loads(line)
@@ -33,8 +33,15 @@ def test_bench_line_contract(device):
     r = d["roofline"]
     assert set(r) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and r["bound"] == "mfma" and r["unit"] == "TFLOP/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.2 < r["frac"] < 1.0
+    assert "traffic_source" in r and (r["traffic"] is None or r["traffic_source"]["commit"])
     c = d["cpu_baseline"]
     assert set(c) >= {"value", "unit", "cores", "kind", "sample"} and c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
+    # the bench checks its own outputs against the oracle: images AND texts, rows from the start, middle and end of the batch
+    assert c["gpu_vs_oracle_min_cosine_images"] > 1 - 1e-3 and c["gpu_vs_oracle_min_cosine_texts"] > 1 - 1e-3
+    rs = d["roofline_sim"]
+    assert rs["bound"] == "mfma" and abs(rs["frac"] - rs["achieved"] / rs["peak"]) < 1e-9 and rs["ms"] > 0
+    assert {"q1024_bf16", "q43000_bf16", "q43000_bf16_rank_only", "q43000_bf16_c3_fused_t2i_t2t"} <= set(d["sim_top10"])
+    assert d["config"]["rccl_ranks"] == 1 and d["config"]["shard_bounds"] == [[0, 43000]] and d["config"]["items_timed"] == 2 * 765
     # images + texts of all ranks / time: 255 gallery items per step = 255 images + 510 texts
     assert abs(d["value"] - 765 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
     assert abs(d["value"] - (d["images_per_s"] + d["texts_per_s"])) / d["value"] < 1e-9

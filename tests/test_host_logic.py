@@ -226,3 +226,67 @@ def test_shard_bounds():
     cover = [shard_bounds(10, 4, r) for r in range(4)]
     assert cover == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert shard_bounds(2, 4, 3) == (2, 2)
+
+
+def test_no_silent_fallback_to_random_weights_or_hash_tokenizer(monkeypatch, tmp_path):
+    """a missing checkpoint, missing base weights or a missing BPE vocabulary must stop the run unless the caller
+    opted in (synthetic data); the reference would have pretrained weights underneath, this build would have random ones."""
+    from knowledge_enhanced_multimodal_retrieval_amd import clip_api, clip_model, tokenizer
+    with pytest.raises(FileNotFoundError):
+        clip_model.load_clip_model("ViT-B/32", checkpoint_path=str(tmp_path / "nope.pt"), device="cpu")
+    monkeypatch.delenv("KEMR_ALLOW_RANDOM_WEIGHTS", raising=False)
+    monkeypatch.delenv("KEMR_ALLOW_HASH_TOKENIZER", raising=False)
+    monkeypatch.delenv("KEMR_CLIP_WEIGHTS", raising=False)
+    clip_api.allow_random_weights(False)
+    tokenizer.allow_hash_tokenizer(False)
+    with pytest.raises(FileNotFoundError, match="no checkpoint available"):
+        clip_api.load("ViT-B/32", device="cpu")
+    with pytest.raises(FileNotFoundError):
+        clip_api.load("ViT-B/32@" + str(tmp_path / "missing.pt"), device="cpu")
+    if tokenizer.find_vocab() is None:
+        monkeypatch.setattr(tokenizer, "_tokenizer", None)
+        with pytest.raises(FileNotFoundError, match="vocabulary"):
+            tokenizer.tokenize(["a bronze statue"])
+        tokenizer.allow_hash_tokenizer(True)
+        try:
+            with pytest.warns(RuntimeWarning):
+                assert tokenizer.tokenize(["a bronze statue"]).shape == (1, 77)
+            assert "hash" in tokenizer.tokenizer_name()
+        finally:
+            tokenizer.allow_hash_tokenizer(False)
+            monkeypatch.setattr(tokenizer, "_tokenizer", None)
+
+
+def test_tokenizer_truncate_and_eot_rule():
+    """clip.tokenize(truncate=True) (reference call sites evaluator.py:126,132): SOT first, EOT last of the kept ids, zero
+    padding; an over-long text is cut to the context and its last id forced to EOT; without truncate it raises.  The cleaning
+    rule (no ftfy offline): html-unescape twice, collapse whitespace, lower-case."""
+    from knowledge_enhanced_multimodal_retrieval_amd import tokenizer
+    t = tokenizer.tokenize(["word " * 300, "one two", ""], truncate=True)
+    assert t.dtype == torch.int32 and t.shape == (3, 77)
+    assert (t[:, 0] == tokenizer.SOT).all()
+    assert t[0, 76] == tokenizer.EOT and (t[0, 1:76] != tokenizer.EOT).all() and (t[0] != 0).all()      # forced EOT, no padding
+    assert t[1, 3] == tokenizer.EOT and (t[1, 4:] == 0).all()
+    assert t[2, 1] == tokenizer.EOT and (t[2, 2:] == 0).all()                                            # empty text: SOT EOT
+    assert int(t[1].argmax()) == 3                                                                        # EOT = the row maximum = the pooled position
+    assert tokenizer.clean("A&amp;amp;B   C\n d ") == "a&b c d"
+    with pytest.raises(RuntimeError, match="too long"):
+        tokenizer.tokenize(["word " * 300])
+
+
+def test_bonus_of_pairs_vectorised_matches_loop():
+    from knowledge_enhanced_multimodal_retrieval_amd import ranking
+    rng = np.random.default_rng(0)
+    nq = 500
+    lens = rng.integers(0, 6, nq)
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate([np.sort(rng.choice(40, l, replace=False)) for l in lens]).astype(np.int32) if ptr[-1] else np.zeros(0, np.int32)
+    val = rng.random(ptr[-1]).astype(np.float32)
+    gt = torch.from_numpy(rng.integers(0, 40, nq).astype(np.int32))
+    got = ranking._bonus_of_pairs((ptr, col, val), gt, torch.device("cpu")).numpy()
+    want = np.zeros(nq, np.float32)
+    for i in range(nq):
+        for j in range(ptr[i], ptr[i + 1]):
+            if col[j] == gt[i]:
+                want[i] += val[j]
+    np.testing.assert_allclose(got, want, rtol=1e-6)

@@ -104,6 +104,25 @@ def test_clip_oracle_matches_hf_fixture(golden_dir, name):
     np.testing.assert_allclose(ot.numpy(), z["text_features"], rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("name", ["ViT-B/32", "ViT-L/14"])
+def test_clip_oracle_matches_hf_fixture_at_full_shape(golden_dir, name):
+    """The oracle at the width / depth / heads / patch the bench and the reference scripts run (the HF pin existed
+    only at the two tiny configurations).  Weights and pixels are regenerated from their seeds and checked by checksum; the
+    expected outputs are transformers.CLIPModel's (the class the reference calls, eval/evaluator_hf.py:115,130,144)."""
+    z = np.load(os.path.join(golden_dir, "clip_hf_full_%s.npz" % name.replace("/", "-")))
+    meta = _json(z, "meta_json")
+    arch = clip_ref.ARCHS[name]
+    sd = clip_ref.random_state_dict(arch, seed=0)
+    for k, v in meta["weight_abs_sums"].items():
+        assert float(sd[k].double().abs().sum()) == pytest.approx(v, rel=1e-12), k
+    px = torch.randn(meta["n_images"], 3, arch["image_size"], arch["image_size"], generator=torch.Generator().manual_seed(meta["pixel_seed"]))
+    assert float(px.double().abs().sum()) == pytest.approx(meta["pixel_abs_sum"], rel=1e-12)
+    ids = torch.from_numpy(z["ids"])
+    assert torch.equal(ids, clip_ref.synthetic_ids(arch, meta["n_texts"]))
+    np.testing.assert_allclose(clip_ref.encode_image(sd, arch, px).numpy(), z["image_features"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(clip_ref.encode_text(sd, arch, ids).numpy(), z["text_features"], rtol=0, atol=2e-5)
+
+
 def test_synthetic_ids_contract():
     arch = clip_ref.ARCHS["ViT-L/14"]
     ids = clip_ref.synthetic_ids(arch, 32)

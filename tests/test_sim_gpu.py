@@ -223,6 +223,49 @@ def test_full_gallery_properties(device):
     assert torch.equal(mi, top_i) and torch.equal(ms, top_s) and torch.equal(ahead8, ahead)
 
 
+@pytest.mark.parametrize("terms", [1, 3])
+def test_full_gallery_fused_two_part_properties(device, terms):
+    """BASELINE configs[2] at the 43k gallery: fused T2I + T2T scoring = ONE contraction over [w_i * image | w_t * target]
+    (kdim 1 536 in bf16, 4 608 as fp32x3; reference metrics.py:145-148).  Size-independent properties as above, plus linearity:
+    the fused pair score is the weighted sum of the two single-part pair scores (exact in fp64 up to the bf16 / fp32x3 error)."""
+    n, d, nq, k, wi, wt = 43000, 768, 512, 10, 0.3, 0.7
+    g = torch.Generator(device="cpu").manual_seed(1)
+    img = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=-1).to(device)
+    tgt = torch.nn.functional.normalize(img.cpu() + 0.5 * torch.randn(n, d, generator=g), dim=-1).to(device)
+    qry = torch.nn.functional.normalize(img[:nq].cpu() + 0.6 * torch.randn(nq, d, generator=g), dim=-1).to(device)
+    qp = engine.build_panel([qry, qry], _lib.SIDE_QUERY, terms, part_scale=[wi, wt])
+    gp = engine.build_panel([img, tgt], _lib.SIDE_GALLERY, terms)
+    assert qp.kdim == 2 * terms * d
+    gt = torch.arange(nq, dtype=torch.int32, device=device)
+    sgt = engine.pair_scores(qp, gp, gt, gt)
+    ahead = torch.zeros(nq, dtype=torch.int32, device=device)
+    top_s, top_i = engine.sim_topk(qp, gp, k, 0, gt, sgt, ahead)
+    rows = torch.arange(nq, device=device).repeat_interleave(k).int()
+    assert torch.equal(engine.pair_scores(qp, gp, rows, top_i.reshape(-1)).view(nq, k), top_s)
+    assert bool((top_s[:, :-1] >= top_s[:, 1:]).all())
+    assert torch.equal((top_i == gt[:, None]).any(dim=1), ahead < k)
+    assert torch.equal(top_i[:, 0] == gt, ahead == 0)
+    # rank-only pass (k = 0) counts the same
+    ahead0 = torch.zeros(nq, dtype=torch.int32, device=device)
+    engine.sim_topk(qp, gp, 0, 0, gt, sgt, ahead0)
+    assert torch.equal(ahead0, ahead)
+    # linearity against fp64
+    want = wi * (qry.double() * img[:nq].double()).sum(-1) + wt * (qry.double() * tgt[:nq].double()).sum(-1)
+    assert float((sgt.double() - want).abs().max()) < (3e-3 if terms == 1 else 2e-6)
+    # 8-way sharding + merge = the single-gallery answer
+    per = (n + 7) // 8
+    ps, pi = [], []
+    ahead8 = torch.zeros(nq, dtype=torch.int32, device=device)
+    for r in range(8):
+        lo, hi = r * per, min(n, (r + 1) * per)
+        gps = engine.build_panel([img[lo:hi], tgt[lo:hi]], _lib.SIDE_GALLERY, terms)
+        s_, i_ = engine.sim_topk(qp, gps, k, lo, gt, sgt, ahead8)
+        ps.append(s_)
+        pi.append(i_)
+    ms, mi = engine.topk_merge(torch.stack(ps, 1), torch.stack(pi, 1), k)
+    assert torch.equal(mi, top_i) and torch.equal(ms, top_s) and torch.equal(ahead8, ahead)
+
+
 @pytest.mark.parametrize("nq,nlists,k", [(1, 336, 10), (3, 400, 10), (64, 26, 10), (1, 128, 32), (5, 336, 1), (70, 336, 10), (2, 30, 10)])
 def test_topk_merge_kernels_match_sort(device, nq, nlists, k):
     """Both merge kernels (wave per query; workgroup per query with the entries in registers, used for few queries and

@@ -14,7 +14,7 @@ shapes = [("v.qkv", B * 257, 3072, 1024, 0), ("v.out", B * 257, 1024, 1024, 0), 
 g = torch.Generator(device=dev).manual_seed(0)
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 orders = [0, 3]          # 0: N fastest; 3: column groups of 4 tiles
-R1 = "r1"                 # the round-1 kernel (temporary variant 10), A/B baseline
+R1 = "v4"                 # gemm256p (variant 4): the round-1 per-tile-prologue kernel as a fixed point of comparison
 
 
 def variant(order, dbg=0):
@@ -48,7 +48,7 @@ for name, m, n, k, epi in shapes:
         out = {}
         for rnd in range(4):
             for o in orders + [R1]:
-                engine.set_gemm_variant(10 if o == R1 else variant(o))
+                engine.set_gemm_variant(4 if o == R1 else variant(o))
                 fn = lambda: engine.op_gemm(a, w, bias, m, epi, c=c)
                 for _ in range(600):
                     fn()
@@ -64,7 +64,7 @@ for name, m, n, k, epi in shapes:
     if what in ("exp",) and name.startswith("v."):
         # timing experiments of the DBG instantiation: 128 = nothing extra (calibrates the instantiation), 8 = no waits for the
         # staged pieces (garbage results), 16 = L2 prefetch PD K-tiles ahead
-        cands = [("prod", variant(0)), ("prod o3", variant(3)), ("dbg", variant(0, dbg=128)), ("r1", 10)]
+        cands = [("order 0", variant(0)), ("order 3", variant(3)), ("order 4", variant(4)), ("dbg", variant(3, dbg=128)), ("v4 (r1 gemm256p)", 4)]
         out = {}
         for rnd in range(3):
             for label, v in cands:
@@ -81,19 +81,17 @@ for name, m, n, k, epi in shapes:
                 out.setdefault(label, []).append(e0.elapsed_time(e1) / 300 * 1e3)
         print("exp", name, {l: "%.1f us (%s)" % (sorted(t)[len(t) // 2], " ".join("%.0f" % x for x in t)) for l, t in out.items()}, flush=True)
     if what in ("all", "clock") and name.startswith("v."):
-        # clock the chip holds under each kernel: in-kernel shader cycles / 100 MHz ticks over the whole launch (wave 0 of every
-        # workgroup), after ~0.2 s of back-to-back launches of that kernel
-        for rnd in range(2):
-            for label, v in (("r1", 10 | (128 << 8)), ("new", variant(0, dbg=128))):
-                engine.set_gemm_variant(v)
-                for _ in range(500):
-                    engine.op_gemm(a, w, bias, m, epi, c=c)
-                torch.cuda.synchronize()
-                buf = (C.c_uint * (256 * 16))()
-                _lib.check(_lib.lib().kemr_debug_gemm_stamps(buf, 256 * 16), "stamps")
-                st = np.frombuffer(buf, dtype=np.uint32).reshape(256, 16).astype(np.float64)
-                cyc, ticks = st[:, 12], st[:, 13]
-                print(f"clock {name} {label}: kernel cycles {np.median(cyc):.0f}, {np.median(ticks) / 100:.1f} us in-kernel, clock {np.median(cyc / ticks) * 0.1:.3f} GHz", flush=True)
+        # clock the chip holds under the kernel: in-kernel shader cycles / 100 MHz ticks over the whole launch (wave 0 of every
+        # workgroup), after ~0.2 s of back-to-back launches
+        engine.set_gemm_variant(variant(3, dbg=128))
+        for _ in range(500):
+            engine.op_gemm(a, w, bias, m, epi, c=c)
+        torch.cuda.synchronize()
+        buf = (C.c_uint * (256 * 16))()
+        _lib.check(_lib.lib().kemr_debug_gemm_stamps(buf, 256 * 16), "stamps")
+        st = np.frombuffer(buf, dtype=np.uint32).reshape(256, 16).astype(np.float64)
+        cyc, ticks = st[:, 12], st[:, 13]
+        print(f"clock {name}: kernel cycles {np.median(cyc):.0f}, {np.median(ticks) / 100:.1f} us in-kernel, clock {np.median(cyc / ticks) * 0.1:.3f} GHz", flush=True)
     if what in ("all", "stamps") and name.startswith("v."):
         for o, fine in ((0, 0), (0, 32)):
             engine.set_gemm_variant(variant(o, dbg=64 | fine))
@@ -112,5 +110,5 @@ for name, m, n, k, epi in shapes:
                 pre = st[:, 10:14] / (tiles * nt)[:, None]
                 line += " | own work before barrier: L1 %.0f, M1 (incl. LDS wait) %.0f, M4 %.0f, M4 + piece wait %.0f" % tuple(np.median(pre, 0))
             print(line, flush=True)
-engine.set_gemm_variant(7 | (1 << 16))
+engine.set_gemm_variant(7 | (4 << 16))      # back to the default tile order (3)
 engine.set_gemm_variant(0)
