@@ -124,8 +124,8 @@ int kemr_encode_text(kemr_model* m, const int32_t* ids_dev, int batch, float* ou
  * terms == 3, stores the bf16 split hi/lo so that the contraction reproduces fp32 products
  * (query panel [hi | lo | hi], gallery panel [hi | hi | lo]); terms == 1 is plain bf16.
  *   kdim = nparts * terms * ceil64(D)
- * A panel buffer must be allocated with its row count rounded up to a multiple of 128
- * (kemr_panel_build zero-fills the pad rows; the kernels read whole 128-row tiles).
+ * A panel buffer must be allocated with its row count rounded up to a multiple of 256
+ * (kemr_panel_build zero-fills the pad rows; the kernels read whole 128- and 256-row tiles).
  * ------------------------------------------------------------------------------------------- */
 typedef enum kemr_panel_side { KEMR_SIDE_QUERY = 0, KEMR_SIDE_GALLERY = 1 } kemr_panel_side;
 
@@ -141,7 +141,8 @@ int kemr_panel_build(const float* const* parts_dev, const float* part_scale, con
  *   q_panel [nq,kdim], g_panel [ng,kdim]
  *   gallery_offset : global id of gallery row 0 (sharded galleries); ids written are global
  *   k <= 32; top_scores/top_idx [nq,k] sorted (score desc, id asc), padded with -inf / -1;
- *   k == 0 = rank only (top_* may be NULL, the ground truth is then required)
+ *   k == 0 = rank only (top_* may be NULL, the ground truth is then required); without a bonus list this is the fast
+ *            256 x 256-tile pass on the encoder GEMM's main loop (same scores, bit for bit)
  *   gt_idx  : optional int32 [nq] GLOBAL candidate id of each query's ground truth
  *   gt_score: optional fp32 [nq]; score of (query, gt) as produced by kemr_pair_scores
  *   ahead   : optional int32 [nq]; += #{j in this gallery : s_ij > s_gt or (s_ij == s_gt and id_j < gt)}

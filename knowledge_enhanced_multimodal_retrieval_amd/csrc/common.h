@@ -109,6 +109,12 @@ struct GemmParams {
     int c_rows_padded;   // C has ceil256(M) writable rows (lets the persistent kernel store without row masks)
     int order;           // gemm256u tile order: 0 = N fastest, else log2(column-group width) + 1 (see gemm256u.hip)
     unsigned* stamps;    // gemm256u DBG instantiation with dbg & 64: per-workgroup cycle sums (tools/)
+    // gemm256u SIM instantiation (rank-only similarity pass): A = query panel [M = nq], W = gallery panel [N = ceil256(ng)]
+    const int32_t* sim_gt;    // [nq] GLOBAL candidate id of each query's ground truth
+    const float* sim_sgt;     // [nq] its score (kemr_pair_scores arithmetic)
+    int32_t* sim_ahead;       // [nq] += candidates of this gallery ranked ahead of it
+    int sim_ng, sim_gbase;    // valid gallery rows; global id of gallery row 0
+    int sim_nchunks, sim_tpc; // gallery chunks per query tile, gallery tiles per chunk
 };
 extern int g_gemm_dbg;
 extern int g_gemm_order;
@@ -118,7 +124,10 @@ int launch_gemm256(const GemmParams& p, int epi, hipStream_t stream);   // gemm2
 int launch_gemm256p(const GemmParams& p, int epi, hipStream_t stream);  // gemm256p.hip: persistent, async epilogue (bf16-store epilogues)
 int launch_gemm256q(const GemmParams& p, int epi, hipStream_t stream);  // gemm256q.hip: persistent, 2 long phases per K-tile
 int launch_gemm256u(const GemmParams& p, int epi, hipStream_t stream);  // gemm256u.hip: gemm256p's K loop, one K-tile pipeline across tiles
-bool gemm256u_fits(const GemmParams& p, int elem_size);               // gemm256u.hip: inside its tile table / 32-bit offsets
+bool gemm256u_fits(const GemmParams& p, int elem_size);
+// rank-only similarity pass on the persistent GEMM's K loop (k == 0, no bonus); false in *used when the shape does not fit it
+int launch_gemm256u_simrank(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, long long gallery_offset,
+                            const int32_t* gt_idx, const float* gt_score, int32_t* ahead, hipStream_t stream, bool* used);               // gemm256u.hip: inside its tile table / 32-bit offsets
 int launch_gemm256u_fp8(const GemmParams& p, int epi, hipStream_t stream);  // gemm256u.hip: fp8 e4m3 operands (A, W in bytes), bf16 C
 int launch_gemm256r(const GemmParams& p, int epi, hipStream_t stream);  // gemm256r.hip: persistent, 4 waves x 128x128, register-staged operands
 int launch_gemm_skinny(const GemmParams& p, int epi, hipStream_t stream);   // gemm_skinny.hip: M <= 512 rows (online queries), split-K over 8 waves

@@ -134,7 +134,12 @@ __device__ unsigned g_gemm_stamp_buf[1024 * 16];      // DBG stamps: [workgroup]
 
 constexpr int GEMM256U_MAX_TILES_PER_WG = 62;         // the tile table is one lane per tile (+ 2 dummies behind the last)
 
-template <int EPI, bool FP8, bool DBG = false>
+// SIM: the same K loop as the scoring half of the path: A = query panel, W = gallery panel (both bf16 [rows, kdim], kdim
+// contiguous: kemr_panel_build), C is never written; the epilogue counts, per query, the candidates of the tile that rank
+// ahead of the query's ground truth (reference metrics.py:13-76: Recall@K / MRR need nothing else).  One workgroup = one
+// 256-query tile x one chunk of gallery tiles (blockIdx = q_tile * nchunks + chunk); same MFMA operand roles and k order as
+// sim_kernel / pair_scores_kernel (sim.hip), so the scores are theirs bit for bit.
+template <int EPI, bool FP8, bool DBG = false, bool SIM = false>
 __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmParams p) {
     constexpr int ES = FP8 ? 1 : 2;          // operand element size
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -190,12 +195,21 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     // arithmetic; the scalar side fetches an entry with v_readlane when a stream enters a tile, so the K loop has no tile
     // arithmetic and no branch.  Lanes behind the last tile hold tile (0, 0): the pointer streams run two K-tiles past the
     // end and stage (valid, unused) data instead of being switched off.
-    const int ntl = (ntiles - (int)blockIdx.x + G - 1) / G;          // tiles of this workgroup, <= GEMM256U_MAX_TILES_PER_WG (host)
+    int ntl = (ntiles - (int)blockIdx.x + G - 1) / G;                // tiles of this workgroup, <= GEMM256U_MAX_TILES_PER_WG (host)
     int t_row = 0, t_col = 0;
-    {
+    int sim_tb = 0;                                                  // SIM: first gallery tile of this workgroup's chunk
+    if constexpr (SIM) {
+        const int qt = (int)blockIdx.x / p.sim_nchunks, chunk = (int)blockIdx.x - qt * p.sim_nchunks;
+        sim_tb = chunk * p.sim_tpc;
+        const int te = min(sim_tb + p.sim_tpc, tiles_n);
+        ntl = te - sim_tb;
+        t_row = qt << 8;
+        t_col = (sim_tb + (lane < ntl ? lane : 0)) << 8;
+    } else {
         const int tidx = (int)blockIdx.x + lane * G;
         if (tidx < ntiles) tile_of(tidx, t_row, t_col);
     }
+    const int t_row_u = __builtin_amdgcn_readfirstlane(t_row);                  // SIM: the workgroup's query tile (the same in every lane)
     const unsigned v_aoff = (unsigned)t_row * (unsigned)(p.lda * ES);          // byte offsets (< 4 GiB: host check)
     const unsigned v_woff = (unsigned)t_col * (unsigned)(p.ldw * ES);
     const unsigned v_coff = ((unsigned)t_row * (unsigned)p.ldc + (unsigned)t_col) * 2u;
@@ -264,6 +278,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     // With the W1 half of K-tile 0 of a tile: that tile's bias (wave 0).  The bias rides with the LAST piece in front of a
     // wait-free stretch, so that nobody waits for it straight after issuing it.
     auto stage_bias = [&]() {
+        if constexpr (SIM) return;
         if (__builtin_expect(tw == nt, 0)) {
             if (wid == 0) {
                 const unsigned boff = ((unsigned)__builtin_amdgcn_readlane(v_bcol, seqw) + lane * 4) * 4u;
@@ -500,8 +515,28 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
         }
     };
 
+    // SIM: per-lane state of the 8 queries a lane holds (rows wr * 128 + mi * 16 + lrow of the query tile)
+    float sgt[8], sgd[8];                          // ground-truth score, and the next float below it (s > sgd  <=>  s >= sgt)
+    int gtid[8], cnt[8];
+    if constexpr (SIM) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) { b4[ni] = u32x4{0u, 0u, 0u, 0u}; asm volatile("" : "+v"(b4[ni])); }
+        int il = lane;
+        asm volatile("" : "+v"(il));
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int q = (t_row_u) + wr * 128 + mi * 16 + (il & 15);
+            const bool ok = q < p.M;
+            gtid[mi] = ok ? p.sim_gt[q] : -1;
+            sgt[mi] = ok ? p.sim_sgt[q] : INFINITY;
+            const unsigned u = __float_as_uint(sgt[mi]);
+            // next float below (finite input, NaN excluded by the host): -0 / +0 -> the smallest negative number
+            sgd[mi] = __uint_as_float((u << 1) == 0u ? 0x80000001u : ((u >> 31) ? u + 1u : u - 1u));
+            cnt[mi] = 0;
+        }
+    }
     for (int seq = 0; seq < ntl; ++seq) {
-        if constexpr (!FP8) {
+        if constexpr (!FP8 && !SIM) {
             // The tile's bias came in with its first W0 piece, which the wait + barrier that closed the previous K-tile (or the
             // prologue) cover; a lane's accumulators cover columns wc * 64 + ni * 16 + lq * 4 .. + 3.
             int il = lane;
@@ -515,92 +550,139 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
         for (int t = 1; t < nt; ++t) ktile(std::false_type{});
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // asm MFMA result -> VALU read (>= 12 wait states)
 
-        // ---- epilogue (lane constants behind an opaque copy of `lane`: recomputed here, not kept across the K loop)
-        int el = lane;
-        asm volatile("" : "+v"(el));
-        const int erow = el & 15, eq = el >> 4;
-        const int er = el >> 3, ec = el & 7;                              // read-back: row er (+8), chunk ec
-        // 16 rows x 128 B per area, chunk ^= row & 7.  Even passes use the area of wave (wid & 3), odd passes that of wave
-        // (wid & 3) + 4 (8 KiB further): the wave's own and its partner's, which is idle (header)
-        const unsigned epi0 = lds_addr(smem + PEPI) + (wid & 3) * 2048;
-        const unsigned epi_w = epi0 + erow * 128 + (((eq >> 1) ^ (erow & 7)) << 4) + (eq & 1) * 8;
-        const unsigned epi_r = epi0 + er * 128 + ((ec ^ er) << 4);        // rows er and er + 8: (er + 8) & 7 == er
-        const unsigned ew0 = epi_w, ew1 = epi_w ^ 32, ew2 = epi_w ^ 64, ew3 = epi_w ^ 96;      // chunk (ni*2 + (eq>>1)) ^ (erow & 7): ni flips bits 5-6
-        const char* const ctile = (const char*)p.C + __builtin_amdgcn_readlane(v_coff, seq) + ((size_t)(wr * 128) * p.ldc + wc * 64) * 2;     // wave-uniform
-        unsigned voff = (unsigned)(er * p.ldc + ec * 8) * 2u;            // + 16 rows per pass
-        const unsigned step8 = (unsigned)p.ldc * 16u;                     // 8 rows in bytes
-        u32x4 bias[4], wsc[4];
-        if constexpr (FP8) {
-            const unsigned bias_r = lds_addr(smem + PBIAS) + (seq & 1) * 1024 + (wc * 64 + eq * 4) * 4;
+        if constexpr (SIM) {
+            // ---- scan: acc[mi][ni][r] = score(query wr*128 + mi*16 + lrow, candidate wc*64 + ni*16 + lq*4 + r of this gallery tile).
+            // Order rule of the whole path: a candidate ranks ahead of the ground truth iff  s > sgt  or  (s == sgt and id < gt).
+            // All of a lane's 16 candidates lie on one side of gt unless gt falls into the lane's 52-id window, so one threshold per
+            // query does (sgd for "ids below gt": >= as >); the rare mixed window and a gallery's ragged last tile are recounted
+            // element by element.
+            int sl = lane;
+            asm volatile("" : "+v"(sl));
+            const int cb = p.sim_gbase + ((sim_tb + seq) << 8) + wc * 64 + (sl >> 4) * 4;       // global id of the lane's first candidate
+            const bool ragged = ((sim_tb + seq + 1) << 8) > p.sim_ng;                            // wave-uniform: some candidates do not exist
+            const int n_end = p.sim_gbase + p.sim_ng;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) bias[ni] = lds_read_b128(bias_r + ni * 64);
+            for (int mi = 0; mi < 8; ++mi) {
+                const int d = gtid[mi] - cb;
+                const float thr = d > 51 ? sgd[mi] : sgt[mi];
+                const bool mixed = (unsigned)d <= 51u;
+                int c = 0;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) wsc[ni] = lds_read_b128(bias_r + (PSCALE - PBIAS) + ni * 64);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wsc[0]), "+v"(wsc[1]), "+v"(wsc[2]), "+v"(wsc[3]) :: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]) :: "memory");
-        }
-        stamp(8);
-        u32x2 o[4];
-        auto pack = [&](const f32x4 (&a4)[4]) {
+                for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                f32x4 v = a4[ni];
-                if constexpr (FP8) {
+                    for (int r = 0; r < 4; ++r) c += acc[mi][ni][r] > thr ? 1 : 0;
+                if (__builtin_amdgcn_ballot_w64(mixed) != 0 || ragged) {
+                    int ce = 0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaf(v[r], __uint_as_float(wsc[ni][r]), __uint_as_float(bias[ni][r]));
+                    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int e = ni * 16 + r;
+                            const float sc = acc[mi][ni][r];
+                            const bool ahead = (cb + e < n_end) && e != d && (sc > sgt[mi] || (sc == sgt[mi] && e < d));
+                            ce += ahead ? 1 : 0;
+                        }
+                    c = (mixed || ragged) ? ce : c;
                 }
-                if constexpr (EPI == EPI_BIAS_QGELU_BF16) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
-                }
-                o[ni][0] = pack_bf16x2(v[0], v[1]);
-                o[ni][1] = pack_bf16x2(v[2], v[3]);
+                cnt[mi] += c;
             }
-        };
-        u32x4 dA0, dA1, dB0, dB1;           // read-back of the pass in flight in each of the two areas
-        // one pass through LDS: 4 writes of the packed quads, 2 reads of whole 16-byte chunks; area B is 8 KiB behind area A
-#define KEMR_LDS_PASS(D0, D1, OFF, OFF1)                                                                                        \
-        asm volatile("ds_write_b64 %2, %6 offset:" #OFF "\n\tds_write_b64 %3, %7 offset:" #OFF "\n\tds_write_b64 %4, %8 offset:" #OFF "\n\t" \
-                     "ds_write_b64 %5, %9 offset:" #OFF "\n\tds_read_b128 %0, %10 offset:" #OFF "\n\tds_read_b128 %1, %10 offset:" #OFF1 \
-                     : "=&v"(D0), "=&v"(D1)                                                                                     \
-                     : "v"(ew0), "v"(ew1), "v"(ew2), "v"(ew3), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(epi_r) : "memory")
-        // wait for a pass's two reads (WAIT = LDS operations of the next pass issued behind them), then its 2 full-line stores.
-        // Non-temporal: C is not read again by this kernel, and written as ordinary write-back lines the 0.1-0.5 GB of a
-        // launch evicts the A / W panels the K loops live on from L2 (round 1, encoder shapes: plain stores +27 % time on QKV,
-        // +17 % on fc1 over no stores at all; `nt` stores +0 % / +6 %; `sc1` write-through +13 %).  Exactly 16 stores per lane
-        // and tile: the vmcnt bookkeeping in the header counts them.  dbg 1 / 4 (DBG instantiation, tools/): stores dropped / plain.
-#define KEMR_STORE_PASS(D0, D1, WAIT)                                                                                           \
-        do {                                                                                                                    \
-            asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" : "+v"(D0), "+v"(D1) :: "memory");                                      \
-            const unsigned voff8 = voff + step8;                                                                                \
-            if (!DBG || !(p.dbg & 1)) {                                                                                         \
-                if (DBG && (p.dbg & 4))                                                                                         \
-                    asm volatile("global_store_dwordx4 %0, %1, %4\n\tglobal_store_dwordx4 %2, %3, %4\n\ts_nop 1"               \
-                                 :: "v"(voff), "v"(D0), "v"(voff8), "v"(D1), "s"(ctile) : "memory");                            \
-                else                                                                                                            \
-                    asm volatile("global_store_dwordx4 %0, %1, %4 nt\n\tglobal_store_dwordx4 %2, %3, %4 nt\n\ts_nop 1"         \
-                                 :: "v"(voff), "v"(D0), "v"(voff8), "v"(D1), "s"(ctile) : "memory");                            \
-            }                                                                                                                   \
-            voff = voff8 + step8;                                                                                               \
-        } while (0)
-        pack(acc[0]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
-        pack(acc[1]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
-        KEMR_STORE_PASS(dA0, dA1, 6); pack(acc[2]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
-        KEMR_STORE_PASS(dB0, dB1, 6); pack(acc[3]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
-        KEMR_STORE_PASS(dA0, dA1, 6); pack(acc[4]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
-        KEMR_STORE_PASS(dB0, dB1, 6); pack(acc[5]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
-        KEMR_STORE_PASS(dA0, dA1, 6); pack(acc[6]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
-        KEMR_STORE_PASS(dB0, dB1, 6); pack(acc[7]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
-        KEMR_STORE_PASS(dA0, dA1, 6);
-        KEMR_STORE_PASS(dB0, dB1, 0);
-#undef KEMR_LDS_PASS
-#undef KEMR_STORE_PASS
+        } else {
+            // ---- epilogue (lane constants behind an opaque copy of `lane`: recomputed here, not kept across the K loop)
+            int el = lane;
+            asm volatile("" : "+v"(el));
+            const int erow = el & 15, eq = el >> 4;
+            const int er = el >> 3, ec = el & 7;                              // read-back: row er (+8), chunk ec
+            // 16 rows x 128 B per area, chunk ^= row & 7.  Even passes use the area of wave (wid & 3), odd passes that of wave
+            // (wid & 3) + 4 (8 KiB further): the wave's own and its partner's, which is idle (header)
+            const unsigned epi0 = lds_addr(smem + PEPI) + (wid & 3) * 2048;
+            const unsigned epi_w = epi0 + erow * 128 + (((eq >> 1) ^ (erow & 7)) << 4) + (eq & 1) * 8;
+            const unsigned epi_r = epi0 + er * 128 + ((ec ^ er) << 4);        // rows er and er + 8: (er + 8) & 7 == er
+            const unsigned ew0 = epi_w, ew1 = epi_w ^ 32, ew2 = epi_w ^ 64, ew3 = epi_w ^ 96;      // chunk (ni*2 + (eq>>1)) ^ (erow & 7): ni flips bits 5-6
+            const char* const ctile = (const char*)p.C + __builtin_amdgcn_readlane(v_coff, seq) + ((size_t)(wr * 128) * p.ldc + wc * 64) * 2;     // wave-uniform
+            unsigned voff = (unsigned)(er * p.ldc + ec * 8) * 2u;            // + 16 rows per pass
+            const unsigned step8 = (unsigned)p.ldc * 16u;                     // 8 rows in bytes
+            u32x4 bias[4], wsc[4];
+            if constexpr (FP8) {
+                const unsigned bias_r = lds_addr(smem + PBIAS) + (seq & 1) * 1024 + (wc * 64 + eq * 4) * 4;
+    #pragma unroll
+                for (int ni = 0; ni < 4; ++ni) bias[ni] = lds_read_b128(bias_r + ni * 64);
+    #pragma unroll
+                for (int ni = 0; ni < 4; ++ni) wsc[ni] = lds_read_b128(bias_r + (PSCALE - PBIAS) + ni * 64);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wsc[0]), "+v"(wsc[1]), "+v"(wsc[2]), "+v"(wsc[3]) :: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]) :: "memory");
+            }
+            stamp(8);
+            u32x2 o[4];
+            auto pack = [&](const f32x4 (&a4)[4]) {
+    #pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    f32x4 v = a4[ni];
+                    if constexpr (FP8) {
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaf(v[r], __uint_as_float(wsc[ni][r]), __uint_as_float(bias[ni][r]));
+                    }
+                    if constexpr (EPI == EPI_BIAS_QGELU_BF16) {
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
+                    }
+                    o[ni][0] = pack_bf16x2(v[0], v[1]);
+                    o[ni][1] = pack_bf16x2(v[2], v[3]);
+                }
+            };
+            u32x4 dA0, dA1, dB0, dB1;           // read-back of the pass in flight in each of the two areas
+            // one pass through LDS: 4 writes of the packed quads, 2 reads of whole 16-byte chunks; area B is 8 KiB behind area A
+    #define KEMR_LDS_PASS(D0, D1, OFF, OFF1)                                                                                        \
+            asm volatile("ds_write_b64 %2, %6 offset:" #OFF "\n\tds_write_b64 %3, %7 offset:" #OFF "\n\tds_write_b64 %4, %8 offset:" #OFF "\n\t" \
+                         "ds_write_b64 %5, %9 offset:" #OFF "\n\tds_read_b128 %0, %10 offset:" #OFF "\n\tds_read_b128 %1, %10 offset:" #OFF1 \
+                         : "=&v"(D0), "=&v"(D1)                                                                                     \
+                         : "v"(ew0), "v"(ew1), "v"(ew2), "v"(ew3), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(epi_r) : "memory")
+            // wait for a pass's two reads (WAIT = LDS operations of the next pass issued behind them), then its 2 full-line stores.
+            // Non-temporal: C is not read again by this kernel, and written as ordinary write-back lines the 0.1-0.5 GB of a
+            // launch evicts the A / W panels the K loops live on from L2 (round 1, encoder shapes: plain stores +27 % time on QKV,
+            // +17 % on fc1 over no stores at all; `nt` stores +0 % / +6 %; `sc1` write-through +13 %).  Exactly 16 stores per lane
+            // and tile: the vmcnt bookkeeping in the header counts them.  dbg 1 / 4 (DBG instantiation, tools/): stores dropped / plain.
+    #define KEMR_STORE_PASS(D0, D1, WAIT)                                                                                           \
+            do {                                                                                                                    \
+                asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" : "+v"(D0), "+v"(D1) :: "memory");                                      \
+                const unsigned voff8 = voff + step8;                                                                                \
+                if (!DBG || !(p.dbg & 1)) {                                                                                         \
+                    if (DBG && (p.dbg & 4))                                                                                         \
+                        asm volatile("global_store_dwordx4 %0, %1, %4\n\tglobal_store_dwordx4 %2, %3, %4\n\ts_nop 1"               \
+                                     :: "v"(voff), "v"(D0), "v"(voff8), "v"(D1), "s"(ctile) : "memory");                            \
+                    else                                                                                                            \
+                        asm volatile("global_store_dwordx4 %0, %1, %4 nt\n\tglobal_store_dwordx4 %2, %3, %4 nt\n\ts_nop 1"         \
+                                     :: "v"(voff), "v"(D0), "v"(voff8), "v"(D1), "s"(ctile) : "memory");                            \
+                }                                                                                                                   \
+                voff = voff8 + step8;                                                                                               \
+            } while (0)
+            pack(acc[0]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+            pack(acc[1]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
+            KEMR_STORE_PASS(dA0, dA1, 6); pack(acc[2]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+            KEMR_STORE_PASS(dB0, dB1, 6); pack(acc[3]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
+            KEMR_STORE_PASS(dA0, dA1, 6); pack(acc[4]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+            KEMR_STORE_PASS(dB0, dB1, 6); pack(acc[5]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
+            KEMR_STORE_PASS(dA0, dA1, 6); pack(acc[6]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+            KEMR_STORE_PASS(dB0, dB1, 6); pack(acc[7]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
+            KEMR_STORE_PASS(dA0, dA1, 6);
+            KEMR_STORE_PASS(dB0, dB1, 0);
+    #undef KEMR_LDS_PASS
+    #undef KEMR_STORE_PASS
+        }
         stamp(9);
     }
 #undef KEMR_DSR
 #undef KEMR_GLDS
 #undef KEMR_STREAM_STEP1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the streams' pieces behind the last K-tile land in LDS: before the exit
+    if constexpr (SIM) {
+        int fl = lane;
+        asm volatile("" : "+v"(fl));
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int q = t_row_u + wr * 128 + mi * 16 + (fl & 15);
+            if (q < p.M && cnt[mi]) atomicAdd(p.sim_ahead + q, cnt[mi]);
+        }
+    }
     if constexpr (DBG) {
         if (clocking && lane == 0) {
 #pragma unroll
@@ -678,6 +760,47 @@ static int launch256u(const GemmParams& p, hipStream_t stream) {
 int gemm_read_stamps(unsigned* host_out, int n_words) {
     if (n_words < 0 || n_words > 1024 * 16) KEMR_FAIL(KEMR_ERR_INVALID, "gemm stamps: at most %d words", 1024 * 16);
     KEMR_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_stamp_buf), (size_t)n_words * 4, 0, hipMemcpyDeviceToHost));
+    return KEMR_OK;
+}
+
+// Rank-only similarity pass (kemr_sim_topk with k == 0 and no bonus list).  Panels must be allocated with their row count
+// rounded up to 256 (include/kemr.h).  *used = false: the shape is outside this kernel (the caller falls back to sim_kernel).
+int launch_gemm256u_simrank(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, long long gallery_offset,
+                            const int32_t* gt_idx, const float* gt_score, int32_t* ahead, hipStream_t stream, bool* used) {
+    *used = false;
+    int num_cu = 0;
+    KEMR_TRY(gemm256u_num_cu(&num_cu));
+    const int q_tiles = (nq + 255) / 256, g_tiles = (ng + 255) / 256;
+    if (kdim % 64 != 0 || kdim < 128 || gallery_offset + ng > 0x7fffffffLL) return KEMR_OK;
+    if ((long)q_tiles * 256 * kdim * 2 >= (1L << 32) || (long)g_tiles * 256 * kdim * 2 >= (1L << 32)) return KEMR_OK;
+    // chunks of the gallery per query tile: as few rounds of workgroups over the CUs as possible, counting half a tile of
+    // prologue per workgroup; a chunk is at most the tile table's size
+    int best_c = 0;
+    double best = 1e30;
+    for (int c = (g_tiles + GEMM256U_MAX_TILES_PER_WG - 1) / GEMM256U_MAX_TILES_PER_WG; c <= g_tiles && c <= 512; ++c) {
+        const int tpc = (g_tiles + c - 1) / c, nch = (g_tiles + tpc - 1) / tpc;
+        const long items = (long)q_tiles * nch;
+        const double cost = (double)((items + num_cu - 1) / num_cu) * (tpc + 0.5);
+        if (cost < best - 1e-9) { best = cost; best_c = nch; }
+    }
+    if (best_c <= 0) return KEMR_OK;
+    GemmParams p{};
+    p.A = q_panel; p.lda = kdim; p.W = g_panel; p.ldw = kdim; p.M = nq; p.N = g_tiles * 256; p.K = kdim;
+    p.sim_gt = gt_idx; p.sim_sgt = gt_score; p.sim_ahead = ahead; p.sim_ng = ng; p.sim_gbase = (int)gallery_offset;
+    p.sim_tpc = (g_tiles + best_c - 1) / best_c;
+    p.sim_nchunks = (g_tiles + p.sim_tpc - 1) / p.sim_tpc;
+    auto kern = gemm256u_bf16_nt_kernel<EPI_BIAS_BF16, false, false, true>;
+    static int attr_dev = -1;
+    int dev = 0;
+    KEMR_CHECK_HIP(hipGetDevice(&dev));
+    if (attr_dev != dev) {
+        KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PSMEM));
+        attr_dev = dev;
+    }
+    ProfScope prof(PROF_SIM, stream);
+    hipLaunchKernelGGL(kern, dim3(q_tiles * p.sim_nchunks), dim3(512), PSMEM, stream, p);
+    KEMR_CHECK_LAUNCH("gemm256u_bf16_nt_kernel<sim>");
+    *used = true;
     return KEMR_OK;
 }
 

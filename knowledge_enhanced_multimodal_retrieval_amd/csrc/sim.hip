@@ -424,7 +424,7 @@ extern "C" int kemr_panel_build(const float* const* parts_dev, const float* part
         a.part_scale[p] = (p < nparts && part_scale) ? part_scale[p] : 1.0f;
         if (p < nparts && !a.parts[p]) KEMR_FAIL(KEMR_ERR_INVALID, "panel_build: part %d is null", p);
     }
-    a.nparts = nparts; a.rows = rows; a.rows_alloc = (int)round_up(rows, 128); a.d = d; a.dpad = (int)round_up(d, 64);
+    a.nparts = nparts; a.rows = rows; a.rows_alloc = (int)round_up(rows, 256); a.d = d; a.dpad = (int)round_up(d, 64);
     a.terms = terms; a.side = side; a.kdim = kemr_panel_kdim(d, nparts, terms);
     const long long total = (long long)a.rows_alloc * nparts * (a.dpad / 2);
     if (total == 0) return KEMR_OK;
@@ -456,7 +456,13 @@ static int launch_sim(const SimParams& p, hipStream_t stream) {
     constexpr int stages = 2 * 2 * ST * SBK * 2, tile = ST * SLD * 4;
     constexpr int smem = stages > tile ? stages : tile;      // the score tile aliases the stages
     auto kern = sim_kernel<KMAX, DENSE>;
-    KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    static int attr_dev = -1;                 // per instantiation; one process drives one device at a time
+    int dev = 0;
+    KEMR_CHECK_HIP(hipGetDevice(&dev));
+    if (attr_dev != dev) {
+        KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_dev = dev;
+    }
     const int q_tiles = (p.nq + ST - 1) / ST;
     ProfScope prof(PROF_SIM, stream);
     hipLaunchKernelGGL(kern, dim3(q_tiles * p.nchunks), dim3(256), smem, stream, p);
@@ -497,6 +503,11 @@ extern "C" int kemr_sim_topk(const void* q_panel_dev, int nq, const void* g_pane
     p.gt_idx = gt_idx_dev; p.gt_score = gt_score_dev; p.ahead = ahead_dev;
     p.brow = bonus_rowptr_dev; p.bcol = bonus_col_dev; p.bval = bonus_val_dev;
     hipStream_t s = (hipStream_t)stream;
+    if (k == 0 && !bonus_rowptr_dev) {        // ranks only: the 256 x 256-tile pass on the persistent GEMM's K loop (gemm256u.hip, SIM)
+        bool used = false;
+        KEMR_TRY(launch_gemm256u_simrank(p.Q, nq, p.G, ng, (int)kdim, gallery_offset, gt_idx_dev, gt_score_dev, ahead_dev, s, &used));
+        if (used) return KEMR_OK;
+    }
     if (k <= 10) KEMR_TRY((launch_sim<10, false>(p, s)));
     else KEMR_TRY((launch_sim<32, false>(p, s)));
     if (k == 0) return KEMR_OK;

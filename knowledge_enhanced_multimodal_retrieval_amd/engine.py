@@ -121,11 +121,11 @@ class ClipEngine:
 # ====================================================================== similarity / ranking ops
 
 def rows_alloc(rows: int) -> int:
-    return (rows + 127) // 128 * 128
+    return (rows + 255) // 256 * 256
 
 
 class Panel:
-    """bf16 operand of the fused similarity kernels: [rows (padded to 128), kdim]."""
+    """bf16 operand of the fused similarity kernels: [rows (padded to 256), kdim]."""
 
     def __init__(self, data: torch.Tensor, rows: int, kdim: int, terms: int, side: int):
         self.data, self.rows, self.kdim, self.terms, self.side = data, rows, kdim, terms, side

@@ -28,7 +28,10 @@ def test_config0_vit_b32_zeroshot_256(device, tmp_path):
         res = main(["--model_name", "ViT-B/32", "--split", "test", "--splits_file", "splits.json", "--batch_size", "64",
                     "--device", "cuda", "--output_file", str(out), "--seed", "42", "--synthetic", "256"])
         saved = json.loads(out.read_text())
-        assert set(saved) == {"model_name", "checkpoint", "split", "tasks", "num_samples", "seed", "metrics"}
+        # the reference's keys (evaluator.py:379-387) + the build's provenance block (what the numbers were computed with)
+        assert set(saved) == {"model_name", "checkpoint", "split", "tasks", "num_samples", "seed", "metrics",
+                              "weights_source", "tokenizer", "precision", "data"}
+        assert saved["weights_source"] == "random(seed 0)" and saved["data"] == "synthetic" and saved["precision"] == "bf16"
         assert saved["num_samples"] == 256 and saved["metrics"] == res["metrics"]
         keys = {f"{t}_{m}" for t in ("T2I", "I2T", "T2T") for m in ("R@1", "R@5", "R@10", "R@20", "MRR", "Mean_Rank")}
         assert set(res["metrics"]) == keys

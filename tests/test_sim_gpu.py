@@ -223,6 +223,48 @@ def test_full_gallery_properties(device):
     assert torch.equal(mi, top_i) and torch.equal(ms, top_s) and torch.equal(ahead8, ahead)
 
 
+@pytest.mark.parametrize("nq,ng,d,terms,off", [(1, 300, 64, 1, 0), (70, 1000, 128, 1, 1000), (300, 5000, 768, 1, 0), (513, 777, 192, 3, 40000),
+                                               (256, 256, 64, 1, 0), (257, 16000, 128, 1, 5), (40, 255, 64, 3, 0)])
+def test_rank_only_fast_path_matches_counting_rule(device, nq, ng, d, terms, off):
+    """k == 0 without a bonus list runs the 256 x 256-tile pass on the encoder GEMM's K loop (gemm256u.hip, SIM).  Its counts
+    must equal (a) the tile kernel's (k > 0 pass over the same panels) and (b) the order rule applied on the host to the dense
+    scores of the same arithmetic: ahead = #{j != gt : s_j > s_gt or (s_j == s_gt and j < gt)} -- with exact ties (duplicated
+    gallery rows on both sides of the ground truth), ragged last tiles, a gallery offset, and accumulation over shards."""
+    g = torch.Generator().manual_seed(nq * 7 + ng)
+    gal = torch.nn.functional.normalize(torch.randn(ng, d, generator=g), dim=-1)
+    gt = torch.randint(0, ng, (nq,), generator=g)
+    for q in range(0, nq, 3):                              # exact ties: copies of the ground-truth row before and after it
+        t = int(gt[q])
+        if t >= 2:
+            gal[t - 2] = gal[t]
+        if t + 3 < ng:
+            gal[t + 3] = gal[t]
+    qry = torch.nn.functional.normalize(gal[gt] + 0.5 * torch.randn(nq, d, generator=g), dim=-1)
+    gal, qry, gt = gal.to(device), qry.to(device), gt.to(device)
+    qp = engine.build_panel([qry], _lib.SIDE_QUERY, terms)
+    gp = engine.build_panel([gal], _lib.SIDE_GALLERY, terms)
+    gtg = (gt + off).int()
+    sgt = engine.pair_scores(qp, gp, torch.arange(nq, device=device).int(), gt.int())
+    fast = torch.zeros(nq, dtype=torch.int32, device=device)
+    engine.sim_topk(qp, gp, 0, off, gtg, sgt, fast)
+    slow = torch.zeros(nq, dtype=torch.int32, device=device)
+    engine.sim_topk(qp, gp, 5, off, gtg, sgt, slow)
+    S = engine.scores_dense(qp, gp)
+    assert torch.equal(S[torch.arange(nq), gt], sgt)
+    ids = torch.arange(ng, device=device)[None, :]
+    want = (((S > sgt[:, None]) | ((S == sgt[:, None]) & (ids < gt[:, None]))) & (ids != gt[:, None])).sum(1).int()
+    assert torch.equal(slow, want)
+    assert torch.equal(fast, want)
+    # two shards accumulate into the same counters
+    if ng >= 512:
+        cut = (ng // 2) // 7 * 7 + 3
+        acc2 = torch.zeros(nq, dtype=torch.int32, device=device)
+        for lo, hi in ((0, cut), (cut, ng)):
+            gps = engine.build_panel([gal[lo:hi]], _lib.SIDE_GALLERY, terms)
+            engine.sim_topk(qp, gps, 0, off + lo, gtg, sgt, acc2)
+        assert torch.equal(acc2, want)
+
+
 @pytest.mark.parametrize("terms", [1, 3])
 def test_full_gallery_fused_two_part_properties(device, terms):
     """BASELINE configs[2] at the 43k gallery: fused T2I + T2T scoring = ONE contraction over [w_i * image | w_t * target]
