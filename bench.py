@@ -109,8 +109,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=255, help="gallery items per rank per step")
     ap.add_argument("--model", default="ViT-L/14")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16-res16", "fp8", "fp8-mlp"],
-                    help="bf16 operands with an fp32 (default) or bf16 residual stream")
+    ap.add_argument("--precision", default=_lib.DEFAULT_PRECISION, choices=["bf16", "bf16-res16", "fp8", "fp8-mlp"],
+                    help="bf16 operands with a bf16 (default, the product's default) or fp32 residual stream; fp8 variants")
     ap.add_argument("--image-slice", type=int, default=0, help="experiment: images per encoder launch (default: the engine's 255)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="A/B only: force a GEMM tile variant (0 = the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -219,7 +219,7 @@ def main():
     # attached only to the configuration it was measured for.
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-    if os.path.exists(tpath) and args.model == "ViT-L/14" and B == 255 and args.precision == "bf16" and args.gemm_variant == 0:
+    if os.path.exists(tpath) and args.model == "ViT-L/14" and B == 255 and args.precision in ("bf16", "bf16-res16") and args.gemm_variant == 0:
         with open(tpath) as f:
             tj = json.load(f)
         traffic, traffic_source = tj.get("bytes_per_launch"), {k: tj.get(k) for k in ("profile", "round", "commit", "algorithmic_bytes_per_launch")}
@@ -307,9 +307,9 @@ def main():
                                   "min_bytes": 2 * GALLERY * arch.embed_dim * 2 + GALLERY * 10 * 8}
 
     # ------------------------------------------------------------------ sub-results: the same step at other precisions
-    if not args.no_extras and args.precision == "bf16":
+    if not args.no_extras and args.precision == _lib.DEFAULT_PRECISION:
         extras = {}
-        for prec in ("bf16-res16", "fp8"):
+        for prec in ("bf16", "fp8"):
             e2 = engine.ClipEngine(arch, dev, precision=prec)
             e2.load_state_dict(random_weights(arch, seed=0))
 
@@ -331,7 +331,7 @@ def main():
                 dt = float(tt.item())
             cos = [float(torch.nn.functional.cosine_similarity(a.double(), b.double()).min()) for a, b in zip(o2, out)]
             extras[prec] = {"items_per_s": 3 * B * world * n2 / dt, "ms_per_step": 1e3 * dt / n2, "steps": n2,
-                            "min_cosine_vs_bf16_image_query_target": cos}
+                            "min_cosine_vs_default_image_query_target": cos}
             del e2
         result["other_precisions"] = extras
 

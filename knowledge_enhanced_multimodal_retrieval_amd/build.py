@@ -18,7 +18,10 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "libkemr.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "gemm256p.hip", "gemm256q.hip", "gemm256w.hip", "gemm256r.hip", "gemm256u.hip", "gemm_skinny.hip", "layernorm.hip", "attention.hip", "embed.hip", "sim.hip", "rank.hip", "preprocess.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "gemm256u.hip", "gemm_skinny.hip", "layernorm.hip", "attention.hip", "embed.hip", "sim.hip", "rank.hip", "preprocess.hip"]
+# Earlier persistent-GEMM generations kept for A/B timing from tools/ only (variants 4, 5, 6, 9 of kemr_set_gemm_variant): built
+# into the library only with `python -m ...build --ab-variants` (or KEMR_BUILD_AB=1), never into the product library.
+AB_SOURCES = ["gemm256p.hip", "gemm256q.hip", "gemm256w.hip", "gemm256r.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "kemr.h")]
 ARCH = "gfx950"
 
@@ -50,10 +53,18 @@ def _compile(src: str, force: bool, extra) -> str:
     return obj
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+def build(force: bool = False, verbose: bool = False, extra_flags=(), ab_variants: bool = False) -> str:
     """Compile every HIP source for gfx950 and link libkemr.so; returns its path."""
+    ab_variants = ab_variants or os.environ.get("KEMR_BUILD_AB", "") == "1"
+    sources = SOURCES + (AB_SOURCES if ab_variants else [])
+    stamp = os.path.join(CSRC, ".ab_variants")
+    if ab_variants != os.path.exists(stamp):         # the flag changes gemm.hip's dispatch: rebuild when it flips
+        force = True
+        (open(stamp, "w").close() if ab_variants else os.remove(stamp))
+    if ab_variants:
+        extra_flags = list(extra_flags) + ["-DKEMR_AB_VARIANTS"]
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force, extra_flags), SOURCES))
+        objs = list(ex.map(lambda s: _compile(s, force, extra_flags), sources))
     if force or _stale(LIB_PATH, objs):
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", LIB_PATH] + objs
         res = subprocess.run(cmd, capture_output=True, text=True)
@@ -65,4 +76,4 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    build(force="--force" in sys.argv, verbose=True, ab_variants="--ab-variants" in sys.argv)

@@ -63,6 +63,11 @@ class VisionTransformer(nn.Module):
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
 
 
+def _lib_default_precision() -> str:
+    from ._lib import DEFAULT_PRECISION
+    return DEFAULT_PRECISION
+
+
 class CLIP(nn.Module):
     def __init__(self, arch: ClipArch, name: str = ""):
         super().__init__()
@@ -144,9 +149,9 @@ class CLIP(nn.Module):
             raise RuntimeError("CLIP: the model sits on %s; the encoders run only on a GPU (model.to('cuda')); there is no "
                                "CPU fallback" % dev)
         if self._engine is None or self._engine.device != dev:
-            # encoder precision of the packed copy: "bf16" unless KEMR_PRECISION says otherwise (bf16-res16 | fp8 | fp8-mlp,
+            # encoder precision of the packed copy: "bf16-res16" unless KEMR_PRECISION says otherwise (bf16 | fp8 | fp8-mlp,
             # kemr_precision in include/kemr.h) -- an environment switch so that the reference's scripts stay unchanged
-            self._engine, self._dirty = ClipEngine(self.arch, dev, precision=os.environ.get("KEMR_PRECISION", "bf16")), True
+            self._engine, self._dirty = ClipEngine(self.arch, dev, precision=os.environ.get("KEMR_PRECISION", _lib_default_precision())), True
         fp = self._fingerprint()
         if self._dirty or fp != getattr(self, "_packed_fp", None):
             self._engine.load_state_dict({k: v for k, v in self.state_dict().items() if k != "logit_scale"})

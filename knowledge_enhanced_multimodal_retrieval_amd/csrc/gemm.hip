@@ -182,9 +182,15 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     const bool bf16_epi = epi == EPI_BIAS_BF16 || epi == EPI_BIAS_QGELU_BF16;
     // a handful of rows (one or a few online queries): 6-24 tiles would leave the chip idle; split K inside the workgroup
     if (bf16_epi && p.c_rows_padded && (g_gemm_variant == 8 || (g_gemm_variant == 0 && p.M <= 512))) return launch_gemm_skinny(p, epi, stream);
+#ifdef KEMR_AB_VARIANTS      // earlier persistent generations, A/B timing from tools/ only (build.py --ab-variants)
     if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 5) return launch_gemm256q(p, epi, stream);
     if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 6) return launch_gemm256w(p, epi, stream);
     if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 9) return launch_gemm256r(p, epi, stream);
+    if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 4) return launch_gemm256p(p, epi, stream);
+#else
+    if (g_gemm_variant == 4 || g_gemm_variant == 5 || g_gemm_variant == 6 || g_gemm_variant == 9)
+        KEMR_FAIL(KEMR_ERR_INVALID, "gemm: variant %d is an A/B kernel that this library was built without (build.py --ab-variants)", g_gemm_variant);
+#endif
     // A ragged last row tile that would cost the persistent kernel one more round over all its workgroups (64 images are
     // 64 x 256 + 64 token rows: 260 tiles of an N = 1024 GEMM on 256 CUs) goes to the skinny kernel instead: measured 4 406 ->
     // 5 320 images/s at 64 images per call (5 650 at 63).
@@ -207,7 +213,6 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
             return launch_gemm_skinny(b, epi, stream);
         }
     }
-    if (can256 && bf16_epi && p.c_rows_padded && g_gemm_variant == 4) return launch_gemm256p(p, epi, stream);
     if (can256 && bf16_epi && p.c_rows_padded && (g_gemm_variant == 7 || (g_gemm_variant == 0 && tiles256 >= 128)) && gemm256u_fits(p, 2))
         return launch_gemm256u(p, epi, stream);
     if (can256 && (g_gemm_variant >= 2 || (g_gemm_variant == 0 && tiles256 >= 128))) return launch_gemm256(p, epi, stream);

@@ -31,8 +31,8 @@ def _require_cuda(t: torch.Tensor, what: str) -> None:
 class ClipEngine:
     """One packed CLIP model (both towers) in HBM."""
 
-    def __init__(self, arch: ClipArch, device: torch.device | str = "cuda:0", precision: str = "bf16"):
-        """precision: "bf16" (fp32 residual stream), "bf16-res16" (bf16 residual stream), "fp8" (QKV GEMMs on fp8
+    def __init__(self, arch: ClipArch, device: torch.device | str = "cuda:0", precision: str = _lib.DEFAULT_PRECISION):
+        """precision: "bf16-res16" (default: bf16 residual stream), "bf16" (fp32 residual stream), "fp8" (QKV GEMMs on fp8
         operands, BASELINE config 5) or "fp8-mlp" (fc1 too); see kemr_precision in include/kemr.h."""
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")

@@ -22,6 +22,7 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader
 
+from . import _lib
 from . import metrics as M
 from . import sparql_fusion as SF
 from .datasets import CLIPEvalDatasetHF, SyntheticRetrievalDataset, collate_fn_eval
@@ -229,7 +230,7 @@ def _run(args, baseline: bool, log_name: str):
                "num_samples": len(dataset), "seed": args.seed, "metrics": metrics,
                # provenance (not in the reference's file): what the numbers were computed with
                "weights_source": getattr(model, "weights_source", "unknown"), "tokenizer": tokenizer.tokenizer_name(),
-               "precision": os.environ.get("KEMR_PRECISION", "bf16"), "data": "synthetic" if args.synthetic > 0 else args.dataset}
+               "precision": os.environ.get("KEMR_PRECISION", _lib.DEFAULT_PRECISION), "data": "synthetic" if args.synthetic > 0 else args.dataset}
     if not baseline:
         results["tasks"] = list(args.tasks)
     save_metrics_to_json(results, args.output_file)
@@ -310,7 +311,7 @@ def main_fusion(argv=None):
                "fusion_checkpoint": args.fusion_checkpoint, "fusion_type": args.fusion_type, "split": args.split,
                "num_samples": len(dataset), "metrics": result,
                "weights_source": getattr(clip_model, "weights_source", "unknown"), "tokenizer": tokenizer.tokenizer_name(),
-               "precision": os.environ.get("KEMR_PRECISION", "bf16"), "data": "synthetic" if args.synthetic > 0 else args.dataset}
+               "precision": os.environ.get("KEMR_PRECISION", _lib.DEFAULT_PRECISION), "data": "synthetic" if args.synthetic > 0 else args.dataset}
     if args.output_file:
         Path(args.output_file).parent.mkdir(parents=True, exist_ok=True)
         with open(args.output_file, "w") as f:

@@ -31,7 +31,7 @@ def test_config0_vit_b32_zeroshot_256(device, tmp_path):
         # the reference's keys (evaluator.py:379-387) + the build's provenance block (what the numbers were computed with)
         assert set(saved) == {"model_name", "checkpoint", "split", "tasks", "num_samples", "seed", "metrics",
                               "weights_source", "tokenizer", "precision", "data"}
-        assert saved["weights_source"] == "random(seed 0)" and saved["data"] == "synthetic" and saved["precision"] == "bf16"
+        assert saved["weights_source"] == "random(seed 0)" and saved["data"] == "synthetic" and saved["precision"] == "bf16-res16"
         assert saved["num_samples"] == 256 and saved["metrics"] == res["metrics"]
         keys = {f"{t}_{m}" for t in ("T2I", "I2T", "T2T") for m in ("R@1", "R@5", "R@10", "R@20", "MRR", "Mean_Rank")}
         assert set(res["metrics"]) == keys
@@ -63,10 +63,10 @@ def test_config0_vit_b32_zeroshot_256(device, tmp_path):
     assert sum(abs(res["metrics"][k] - exact[k]) > 1e-9 for k in exact) <= 4
 
 
-@pytest.mark.parametrize("precision", ["bf16-res16", "fp8", "fp8-mlp"])
+@pytest.mark.parametrize("precision", ["bf16", "fp8", "fp8-mlp"])
 def test_precision_switch_reaches_the_drop_in_modules(device, tmp_path, monkeypatch, precision):
     """KEMR_PRECISION selects the encoder precision behind the unchanged CLI: the evaluator runs and its
-    embeddings differ from the bf16 run by what that precision costs, no more."""
+    embeddings differ from the default (bf16 operands, bf16 residual stream) run by what that precision costs, no more."""
     import clip
     from knowledge_enhanced_multimodal_retrieval_amd import datasets, evaluators
     ds = datasets.SyntheticRetrievalDataset(64, 224, seed=7)
@@ -74,12 +74,13 @@ def test_precision_switch_reaches_the_drop_in_modules(device, tmp_path, monkeypa
         warnings.simplefilter("ignore")
         monkeypatch.delenv("KEMR_PRECISION", raising=False)
         base, _ = clip.load("ViT-B/32", device="cuda")
+        assert base.engine().precision == "bf16-res16"
         ref_img, ref_qry, _, _ = evaluators.encode_dataset(base, ds, 32, 7)
         monkeypatch.setenv("KEMR_PRECISION", precision)
         model, _ = clip.load("ViT-B/32", device="cuda")
         assert model.engine().precision == precision
         img, qry, _, _ = evaluators.encode_dataset(model, ds, 32, 7)
-    tol = {"bf16-res16": 1e-3, "fp8": 5e-3, "fp8-mlp": 2e-2}[precision]
+    tol = {"bf16": 1e-3, "fp8": 5e-3, "fp8-mlp": 2e-2}[precision]
     di, dq = float((1 - _cos(img, ref_img)).max()), float((1 - _cos(qry, ref_qry)).max())
     assert 0 < di < tol and 0 < dq < tol
 

@@ -15,7 +15,7 @@ def _bf16_round(x):
 
 @pytest.mark.parametrize("m,n,k", [(257, 256, 256), (300, 768, 256), (1000, 1024, 1024), (514, 256, 1024), (63 * 257, 1024, 1024)])
 @pytest.mark.parametrize("epi", [_lib.EPI_BIAS_BF16, _lib.EPI_BIAS_QGELU_BF16, _lib.EPI_BIAS_RESID_F32])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 7])
 def test_gemm_epilogues(device, m, n, k, epi, variant):
     engine.set_gemm_variant(variant)      # 1: 128x128 tiles, 2: 256x256 tiles (every N here is a multiple of 256)
     try:
@@ -50,7 +50,7 @@ def _gemm_epilogue_case(device, m, n, k, epi):
     # bf16 epilogues: rows in [m, m_alloc) are scratch (the persistent kernel stores whole tiles)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 7])
 def test_gemm_identity_asymmetric(device, variant):
     """A = I against an asymmetric W catches transposed / permuted fragment maps (cdna guide section 3)."""
     k = n = 512
@@ -66,7 +66,7 @@ def test_gemm_identity_asymmetric(device, variant):
     assert torch.equal(out.float().cpu(), w.T.contiguous().to(torch.bfloat16).float())
 
 
-@pytest.mark.parametrize("variant", [4, 5, 6, 7, 9])
+@pytest.mark.parametrize("variant", [7])
 def test_gemm_persistent_many_tiles_per_cu(device, variant):
     """Persistent kernel: > 256 tiles so that every workgroup walks several tiles (hand-over path), ragged M, with and
     without bias, both bf16 epilogues."""
@@ -111,7 +111,7 @@ def test_gemm256_short_and_long_k(device, k, variant):
     assert float((out.cpu()[:m] - ref).abs().max()) < 2e-4 * (1 + float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [6, 7, 9])
+@pytest.mark.parametrize("variant", [7])
 @pytest.mark.parametrize("k", [128, 192, 320, 4096])
 def test_gemm_cross_tile_pipeline_k_tiles(device, k, variant):
     """Persistent kernels whose K-tile pipeline runs across tile switches: 2, 3, 5 (odd: the LDS buffer parity flips
@@ -213,6 +213,16 @@ def test_gemm_rejects_bad_shapes(device):
     w = torch.zeros(128, 96, dtype=torch.bfloat16, device=device)
     with pytest.raises(RuntimeError, match="K % 64"):
         engine.op_gemm(a, w, None, 10, _lib.EPI_BIAS_BF16)
+    # the earlier persistent generations (variants 4, 5, 6, 9) are A/B kernels for tools/: not in the product library
+    a = torch.zeros(512, 256, dtype=torch.bfloat16, device=device)
+    w = torch.zeros(256, 256, dtype=torch.bfloat16, device=device)
+    for v in (4, 5, 6, 9):
+        engine.set_gemm_variant(v)
+        try:
+            with pytest.raises(RuntimeError, match="A/B kernel"):
+                engine.op_gemm(a, w, None, 512, _lib.EPI_BIAS_BF16)
+        finally:
+            engine.set_gemm_variant(0)
 
 
 @pytest.mark.parametrize("width", [256, 512, 768, 1024])

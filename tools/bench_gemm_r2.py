@@ -14,7 +14,7 @@ shapes = [("v.qkv", B * 257, 3072, 1024, 0), ("v.out", B * 257, 1024, 1024, 0), 
 g = torch.Generator(device=dev).manual_seed(0)
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 orders = [0, 3]          # 0: N fastest; 3: column groups of 4 tiles
-R1 = "v4"                 # gemm256p (variant 4): the round-1 per-tile-prologue kernel as a fixed point of comparison
+R1 = "v2"                 # gemm256 (variant 2, non-persistent lockstep kernel): a fixed point of comparison in the product library
 
 
 def variant(order, dbg=0):
@@ -48,7 +48,7 @@ for name, m, n, k, epi in shapes:
         out = {}
         for rnd in range(4):
             for o in orders + [R1]:
-                engine.set_gemm_variant(4 if o == R1 else variant(o))
+                engine.set_gemm_variant(2 if o == R1 else variant(o))
                 fn = lambda: engine.op_gemm(a, w, bias, m, epi, c=c)
                 for _ in range(600):
                     fn()
@@ -64,7 +64,7 @@ for name, m, n, k, epi in shapes:
     if what in ("exp",) and name.startswith("v."):
         # timing experiments of the DBG instantiation: 128 = nothing extra (calibrates the instantiation), 8 = no waits for the
         # staged pieces (garbage results), 16 = L2 prefetch PD K-tiles ahead
-        cands = [("order 0", variant(0)), ("order 3", variant(3)), ("order 4", variant(4)), ("dbg", variant(3, dbg=128)), ("v4 (r1 gemm256p)", 4)]
+        cands = [("order 0", variant(0)), ("order 3", variant(3)), ("order 4", variant(4)), ("dbg", variant(3, dbg=128)), ("v2 (gemm256 lockstep)", 2)]
         out = {}
         for rnd in range(3):
             for label, v in cands:
