@@ -56,8 +56,9 @@ typedef enum kemr_dtype { KEMR_F32 = 0, KEMR_BF16 = 1, KEMR_I32 = 2, KEMR_FP8 = 
  * KEMR_PREC_FP8_MLP:    the fc1 GEMMs as well (56 % of the FLOPs in fp8, +25 % encode throughput); on the synthetic
  *                       near-duplicate retrieval test this costs about one point of Recall@10 where bf16 is below 90 %
  *                       (the MLP update goes straight into the residual stream, the QKV error is averaged by the softmax),
- *                       so it is outside config 5's bar and opt-in. */
-typedef enum kemr_precision { KEMR_PREC_BF16 = 1, KEMR_PREC_BF16_RES16 = 2, KEMR_PREC_FP8 = 3, KEMR_PREC_FP8_MLP = 4 } kemr_precision;
+ *                       so it is outside config 5's bar and opt-in.
+ * KEMR_PREC_FP8_RES16:  KEMR_PREC_FP8 with the bf16 residual stream of KEMR_PREC_BF16_RES16 (the two savings add). */
+typedef enum kemr_precision { KEMR_PREC_BF16 = 1, KEMR_PREC_BF16_RES16 = 2, KEMR_PREC_FP8 = 3, KEMR_PREC_FP8_MLP = 4, KEMR_PREC_FP8_RES16 = 5 } kemr_precision;
 
 typedef enum kemr_tower { KEMR_TOWER_VISION = 0, KEMR_TOWER_TEXT = 1 } kemr_tower;
 
@@ -221,6 +222,13 @@ typedef enum kemr_epilogue {
 size_t kemr_preprocess_workspace_bytes(int height, int width, int n_px);
 int kemr_preprocess_u8(const unsigned char* img_dev, int height, int width, int n_px, float* out_dev,
                        void* workspace_dev, size_t workspace_bytes, void* stream);
+/* A whole loader batch in ONE launch pair: `batch` uint8 HWC images of any sizes packed back to back in packed_dev
+ * (image b starts at byte offsets[b] and has heights[b] x widths[b] pixels; the three arrays are HOST arrays) ->
+ * out_dev fp32 [batch, 3, n_px, n_px].  Same arithmetic, bit for bit, as kemr_preprocess_u8 per image. */
+size_t kemr_preprocess_batch_workspace_bytes(const int32_t* heights, const int32_t* widths, int batch, int n_px);
+int kemr_preprocess_u8_batch(const unsigned char* packed_dev, const int64_t* offsets, const int32_t* heights,
+                             const int32_t* widths, int batch, int n_px, float* out_dev, void* workspace_dev,
+                             size_t workspace_bytes, void* stream);
 
 /* tile variant used by every GEMM launch: 0 = automatic (default: 7 for the bf16 epilogues from 128 tiles up), 1 = 128x128x64
  * / 4 waves, 2 = 256x256x64 / 8 waves in lockstep, 3 = the same with staggered wave halves, 4 / 5 = persistent 256x256 with a

@@ -20,10 +20,11 @@ PREC_BF16 = 1
 PREC_BF16_RES16 = 2
 PREC_FP8 = 3
 PREC_FP8_MLP = 4
+PREC_FP8_RES16 = 5
 # default of the product: bf16 GEMM / attention operands AND a bf16 residual stream (LayerNorm statistics and the residual add stay
 # fp32): at the bench shape 1 - cos against the fp32 oracle is 4e-5 (bar 1e-3) for +3.7 % throughput; "bf16" keeps the stream fp32
 DEFAULT_PRECISION = "bf16-res16"
-PRECISIONS = {"bf16": PREC_BF16, "bf16-res16": PREC_BF16_RES16, "fp8": PREC_FP8, "fp8-mlp": PREC_FP8_MLP}
+PRECISIONS = {"bf16": PREC_BF16, "bf16-res16": PREC_BF16_RES16, "fp8": PREC_FP8, "fp8-mlp": PREC_FP8_MLP, "fp8-res16": PREC_FP8_RES16}
 TOWER_VISION, TOWER_TEXT = 0, 1
 SIDE_QUERY, SIDE_GALLERY = 0, 1
 EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RESID_F32 = 0, 1, 2
@@ -66,6 +67,8 @@ SIGNATURES = {
     "kemr_op_gemm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "kemr_preprocess_workspace_bytes": (_sz, [_i, _i, _i]),
     "kemr_preprocess_u8": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "kemr_preprocess_batch_workspace_bytes": (_sz, [_vp, _vp, _i, _i]),
+    "kemr_preprocess_u8_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "kemr_op_gemm_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "kemr_op_e4m3_host": (_i, [_vp, _vp, C.c_longlong]),
     "kemr_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -190,9 +190,9 @@ extern "C" int kemr_model_load_tensor(kemr_model* m, const char* name, const voi
 
 extern "C" int kemr_model_finalize(kemr_model* m, int precision) {
     if (!m) KEMR_FAIL(KEMR_ERR_INVALID, "finalize: null model");
-    if (precision < KEMR_PREC_BF16 || precision > KEMR_PREC_FP8_MLP)
+    if (precision < KEMR_PREC_BF16 || precision > KEMR_PREC_FP8_RES16)
         KEMR_FAIL(KEMR_ERR_INVALID, "finalize: unsupported precision %d", precision);
-    const int fp8 = precision == KEMR_PREC_FP8 ? 1 : precision == KEMR_PREC_FP8_MLP ? 3 : 0;
+    const int fp8 = (precision == KEMR_PREC_FP8 || precision == KEMR_PREC_FP8_RES16) ? 1 : precision == KEMR_PREC_FP8_MLP ? 3 : 0;
     if (fp8 && ((m->cfg.v_width % 128) || (m->cfg.t_width % 128) || m->cfg.v_width < 256 || m->cfg.t_width < 256))
         KEMR_FAIL(KEMR_ERR_INVALID, "finalize: fp8 needs tower widths that are multiples of 128 and >= 256");
     for (const auto& n : m->names)
@@ -295,7 +295,7 @@ extern "C" int kemr_model_finalize(kemr_model* m, int precision) {
     m->lnf_g = F("ln_final.weight"); m->lnf_b = F("ln_final.bias"); m->tproj = F("text_projection");
 
     for (auto& kv : m->tensors) { std::vector<float>().swap(kv.second.data); kv.second.loaded = false; }
-    m->res_dtype = precision == KEMR_PREC_BF16_RES16 ? KEMR_BF16 : KEMR_F32;
+    m->res_dtype = (precision == KEMR_PREC_BF16_RES16 || precision == KEMR_PREC_FP8_RES16) ? KEMR_BF16 : KEMR_F32;
     m->fp8 = fp8;
     m->finalized = true;
     return KEMR_OK;

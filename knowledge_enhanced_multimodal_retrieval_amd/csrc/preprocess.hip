@@ -9,6 +9,7 @@
 // accumulation.  Only the input rows the vertical pass needs are filtered horizontally.
 #include "common.h"
 
+#include <array>
 #include <cmath>
 #include <map>
 #include <mutex>
@@ -166,11 +167,150 @@ __global__ __launch_bounds__(256) void preprocess_v_kernel(const uint8_t* __rest
     out[2 * plane + gid] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)v2, 255.0f), m2), d2);
 }
 
+// ---- one launch pair per BATCH: images of any sizes packed back to back, one descriptor per image ----------------------
+struct PreImg {
+    long long img_off;     // byte offset of the image in the packed uint8 buffer
+    long long temp_off;    // byte offset of its horizontally filtered rows in the temp area
+    int width, row_lo, rows, left, top;
+    int ksize_h, resample_h, ksize_v, resample_v;
+    int tab_hk, tab_hb, tab_vk, tab_vb;      // int32 offsets of its plan's tables in the table area
+    int pad;
+};
+static_assert(sizeof(PreImg) == 72, "descriptor layout");
+
+__global__ __launch_bounds__(256) void preprocess_h_batch_kernel(const uint8_t* __restrict__ packed, const PreImg* __restrict__ desc,
+                                                                 const int32_t* __restrict__ tab, uint8_t* __restrict__ temp_all, int n) {
+    const PreImg d = desc[blockIdx.y];
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= d.rows * n) return;
+    const int r = gid / n, xx = gid - r * n;
+    const uint8_t* src = packed + d.img_off + ((size_t)(d.row_lo + r) * d.width) * 3;
+    uint8_t* dst = temp_all + d.temp_off + ((size_t)r * n + xx) * 3;
+    if (!d.resample_h) {
+        const uint8_t* s = src + (size_t)(d.left + xx) * 3;
+        dst[0] = s[0]; dst[1] = s[1]; dst[2] = s[2];
+        return;
+    }
+    const int32_t* bounds = tab + d.tab_hb;
+    const int xmin = bounds[2 * xx], cnt = bounds[2 * xx + 1];
+    const int32_t* k = tab + d.tab_hk + (size_t)xx * d.ksize_h;
+    int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+    for (int x = 0; x < cnt; ++x) {
+        const uint8_t* s = src + (size_t)(xmin + x) * 3;
+        const int c = k[x];
+        s0 += s[0] * c; s1 += s[1] * c; s2 += s[2] * c;
+    }
+    dst[0] = (uint8_t)clip8(s0 >> PRECISION_BITS); dst[1] = (uint8_t)clip8(s1 >> PRECISION_BITS); dst[2] = (uint8_t)clip8(s2 >> PRECISION_BITS);
+}
+
+__global__ __launch_bounds__(256) void preprocess_v_batch_kernel(const PreImg* __restrict__ desc, const int32_t* __restrict__ tab,
+                                                                 const uint8_t* __restrict__ temp_all, int n, float m0, float m1, float m2,
+                                                                 float d0, float d1, float d2, float* __restrict__ out_all) {
+    const PreImg d = desc[blockIdx.y];
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n * n) return;
+    const int yy = gid / n, xx = gid - yy * n;
+    const uint8_t* temp = temp_all + d.temp_off;
+    int v0, v1, v2;
+    if (!d.resample_v) {
+        const uint8_t* s = temp + ((size_t)(d.top + yy - d.row_lo) * n + xx) * 3;
+        v0 = s[0]; v1 = s[1]; v2 = s[2];
+    } else {
+        const int32_t* bounds = tab + d.tab_vb;
+        const int ymin = bounds[2 * yy], cnt = bounds[2 * yy + 1];
+        const int32_t* k = tab + d.tab_vk + (size_t)yy * d.ksize_v;
+        int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+        for (int y = 0; y < cnt; ++y) {
+            const uint8_t* s = temp + ((size_t)(ymin + y - d.row_lo) * n + xx) * 3;
+            const int c = k[y];
+            s0 += s[0] * c; s1 += s[1] * c; s2 += s[2] * c;
+        }
+        v0 = clip8(s0 >> PRECISION_BITS); v1 = clip8(s1 >> PRECISION_BITS); v2 = clip8(s2 >> PRECISION_BITS);
+    }
+    const size_t plane = (size_t)n * n;
+    float* out = out_all + (size_t)blockIdx.y * 3 * plane;
+    out[gid] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)v0, 255.0f), m0), d0);
+    out[plane + gid] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)v1, 255.0f), m1), d1);
+    out[2 * plane + gid] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)v2, 255.0f), m2), d2);
+}
+
+// host side of a batch: descriptors + the tables of the distinct sizes, and where everything lives in the workspace
+struct BatchLayout {
+    std::vector<PreImg> desc;
+    std::vector<int32_t> tables;
+    size_t tab_off = 0, temp_off = 0, bytes = 0;
+    int max_rows = 0;
+};
+
+int layout_batch(const int32_t* heights, const int32_t* widths, const int64_t* offsets, int batch, int n, BatchLayout& L) {
+    std::map<std::pair<int, int>, std::array<int, 4>> seen;       // (h, w) -> table offsets of its plan
+    L.desc.resize(batch);
+    size_t temp = 0;
+    for (int b = 0; b < batch; ++b) {
+        const int h = heights[b], w = widths[b];
+        if (h <= 0 || w <= 0 || h > 32768 || w > 32768) KEMR_FAIL(KEMR_ERR_INVALID, "preprocess batch: bad image size %d x %d (image %d)", h, w, b);
+        const Plan& p = plan_for(h, w, n);
+        auto it = seen.find({h, w});
+        if (it == seen.end()) {
+            const int base = (int)L.tables.size();
+            L.tables.insert(L.tables.end(), p.table.begin(), p.table.end());
+            it = seen.emplace(std::make_pair(h, w), std::array<int, 4>{base, base + (int)p.off_hb, base + (int)p.off_vk, base + (int)p.off_vb}).first;
+        }
+        PreImg& d = L.desc[b];
+        d.img_off = offsets ? offsets[b] : 0;
+        d.temp_off = (long long)temp;
+        d.width = w; d.row_lo = p.vy.in_lo; d.rows = p.vy.in_hi - p.vy.in_lo; d.left = p.left; d.top = p.top;
+        d.ksize_h = p.hx.ksize; d.resample_h = p.hx.resample ? 1 : 0; d.ksize_v = p.vy.ksize; d.resample_v = p.vy.resample ? 1 : 0;
+        d.tab_hk = it->second[0]; d.tab_hb = it->second[1]; d.tab_vk = it->second[2]; d.tab_vb = it->second[3];
+        d.pad = 0;
+        temp += (size_t)round_up((int64_t)d.rows * n * 3, 16);
+        if (d.rows > L.max_rows) L.max_rows = d.rows;
+    }
+    L.tab_off = (size_t)round_up((int64_t)batch * sizeof(PreImg), 256);
+    L.temp_off = L.tab_off + (size_t)round_up((int64_t)L.tables.size() * 4, 256);
+    L.bytes = L.temp_off + (size_t)round_up((int64_t)temp, 256);
+    return KEMR_OK;
+}
+
 }  // namespace
 
 }  // namespace kemr
 
 using namespace kemr;
+
+extern "C" size_t kemr_preprocess_batch_workspace_bytes(const int32_t* heights, const int32_t* widths, int batch, int n_px) {
+    if (!heights || !widths || batch <= 0 || n_px <= 0 || n_px > 1024) return 0;
+    BatchLayout L;
+    if (layout_batch(heights, widths, nullptr, batch, n_px, L) != KEMR_OK) return 0;
+    return L.bytes;
+}
+
+extern "C" int kemr_preprocess_u8_batch(const unsigned char* packed_dev, const int64_t* offsets, const int32_t* heights,
+                                        const int32_t* widths, int batch, int n_px, float* out_dev, void* workspace_dev,
+                                        size_t workspace_bytes, void* stream) {
+    if (batch == 0) return KEMR_OK;
+    if (!packed_dev || !offsets || !heights || !widths || !out_dev || batch < 0) KEMR_FAIL(KEMR_ERR_INVALID, "preprocess batch: null argument");
+    if (n_px <= 0 || n_px > 1024) KEMR_FAIL(KEMR_ERR_INVALID, "preprocess batch: bad output size %d", n_px);
+    BatchLayout L;
+    KEMR_TRY(layout_batch(heights, widths, offsets, batch, n_px, L));
+    if (!workspace_dev || workspace_bytes < L.bytes) KEMR_FAIL(KEMR_ERR_WORKSPACE, "preprocess batch: workspace too small: %zu < %zu bytes", workspace_bytes, L.bytes);
+    if ((uintptr_t)workspace_dev % 256) KEMR_FAIL(KEMR_ERR_WORKSPACE, "preprocess batch: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace_dev;
+    // descriptors and tables: pageable host memory is staged before hipMemcpyAsync returns, so the vectors may go out of scope
+    KEMR_CHECK_HIP(hipMemcpyAsync(ws, L.desc.data(), L.desc.size() * sizeof(PreImg), hipMemcpyHostToDevice, s));
+    if (!L.tables.empty()) KEMR_CHECK_HIP(hipMemcpyAsync(ws + L.tab_off, L.tables.data(), L.tables.size() * 4, hipMemcpyHostToDevice, s));
+    const int n = n_px;
+    ProfScope prof(PROF_OTHER, s);
+    hipLaunchKernelGGL(preprocess_h_batch_kernel, dim3((unsigned)(((size_t)L.max_rows * n + 255) / 256), (unsigned)batch), dim3(256), 0, s,
+                       packed_dev, (const PreImg*)ws, (const int32_t*)(ws + L.tab_off), (uint8_t*)(ws + L.temp_off), n);
+    KEMR_CHECK_LAUNCH("preprocess_h_batch_kernel");
+    hipLaunchKernelGGL(preprocess_v_batch_kernel, dim3((unsigned)((n * n + 255) / 256), (unsigned)batch), dim3(256), 0, s,
+                       (const PreImg*)ws, (const int32_t*)(ws + L.tab_off), (const uint8_t*)(ws + L.temp_off), n, 0.48145466f, 0.4578275f,
+                       0.40821073f, 0.26862954f, 0.26130258f, 0.27577711f, out_dev);
+    KEMR_CHECK_LAUNCH("preprocess_v_batch_kernel");
+    return KEMR_OK;
+}
 
 extern "C" size_t kemr_preprocess_workspace_bytes(int height, int width, int n_px) {
     if (height <= 0 || width <= 0 || n_px <= 0 || height > 32768 || width > 32768 || n_px > 1024) return 0;

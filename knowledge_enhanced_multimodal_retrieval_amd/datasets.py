@@ -82,14 +82,53 @@ class SyntheticRetrievalDataset(Dataset):
         return image, query, target, f"synthetic-{idx:06d}"
 
 
+class SyntheticRawImageDataset(Dataset):
+    """The same texts as :class:`SyntheticRetrievalDataset`, with the image as a camera-like uint8 ``[H, W, 3]`` array of a
+    seeded size (the reference's dataset returns PIL images of whatever size the file has, clip_dataset.py:110-125): the
+    input of the device-side preprocessing."""
+
+    SIZES = ((375, 500), (500, 375), (480, 640), (333, 500), (256, 256), (600, 800), (224, 224), (427, 640))
+
+    def __init__(self, n: int, seed: int = 42):
+        self.n, self.seed = n, seed
+        self._texts = SyntheticRetrievalDataset(n, 8, seed)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, idx):
+        import numpy as np
+        rng = np.random.default_rng(self.seed * 1_000_003 + idx)
+        h, w = self.SIZES[int(rng.integers(0, len(self.SIZES)))]
+        # smooth-ish content: a coarse random field upsampled by repetition + noise (resampling noise alone tests little)
+        coarse = rng.integers(0, 256, size=((h + 15) // 16, (w + 15) // 16, 3), dtype=np.uint8)
+        image = np.repeat(np.repeat(coarse, 16, axis=0), 16, axis=1)[:h, :w]
+        image = image ^ rng.integers(0, 32, size=(h, w, 1), dtype=np.uint8)
+        _, query, target, uid = self._texts[idx]
+        return torch.from_numpy(np.ascontiguousarray(image)), query, target, uid
+
+
 def collate_fn_eval(batch):
     images, queries, targets, uuids = zip(*batch)
     if torch.is_tensor(images[0]) and images[0].dtype == torch.uint8:      # raw [H, W, 3] images of any size (preprocess.RawRGB):
-        return list(images), list(queries), list(targets), list(uuids)    # preprocessed on the GPU by encode_dataset
+        from .preprocess import pack_raw                                   # one flat pinned-able buffer per batch,
+        return pack_raw(images), list(queries), list(targets), list(uuids)    # preprocessed on the GPU by encode_dataset
     return torch.stack(images, dim=0), list(queries), list(targets), list(uuids)
 
 
 collate_fn_train = collate_fn_eval
+
+
+class CollateAndTokenize:
+    """``collate_fn_eval`` + tokenisation of both text columns INSIDE the loader worker (evaluator.py:126,132 tokenises in
+    the main process between two encoder calls): the main process then only queues copies and kernels."""
+
+    def __init__(self, tokenize_fn):
+        self.tokenize_fn = tokenize_fn
+
+    def __call__(self, batch):
+        images, queries, targets, uuids = collate_fn_eval(batch)
+        return images, self.tokenize_fn(queries), self.tokenize_fn(targets), uuids
 
 
 def collate_fn_eval_texts(batch):

@@ -25,7 +25,8 @@ from torch.utils.data import DataLoader
 from . import _lib
 from . import metrics as M
 from . import sparql_fusion as SF
-from .datasets import CLIPEvalDatasetHF, SyntheticRetrievalDataset, collate_fn_eval
+from .datasets import CLIPEvalDatasetHF, CollateAndTokenize, SyntheticRawImageDataset, SyntheticRetrievalDataset, collate_fn_eval
+from .preprocess import ClipPreprocessGPU, PackedRaw
 from .logging_utils import save_metrics_to_json, setup_logger
 
 logger = logging.getLogger(__name__)
@@ -68,9 +69,12 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
     tokenize_fn = tokenize_fn or default_tokenize
     g = torch.Generator()
     g.manual_seed(seed)
+    # Tokenisation rides in the loader (in its worker processes when there are any), so does packing raw images into one
+    # buffer; the pin thread pins both.  What is left on this thread per loader batch: three async copies and the launches.
     loader = DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers,
-                        pin_memory=device.type == "cuda", collate_fn=collate_fn_eval,
-                        worker_init_fn=seed_worker if num_workers else None, generator=g)
+                        pin_memory=device.type == "cuda", collate_fn=CollateAndTokenize(tokenize_fn),
+                        worker_init_fn=seed_worker if num_workers else None, generator=g,
+                        prefetch_factor=4 if num_workers else None, persistent_workers=False)
     img, qry, tgt, uuids = [], [], [], []
     logger.info(f"Computing embeddings for {len(dataset)} samples...")
     # The loader's batch size is the host pipeline's business (the reference scripts pass 64); the encoders are fed
@@ -92,15 +96,14 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
         pending -= take
 
     gpu_pre = None
-    for images, queries, targets, ids in loader:
-        if isinstance(images, list):           # raw uint8 images (preprocess.RawRGB): resize / crop / normalise on the device
-            if gpu_pre is None:
-                from .preprocess import ClipPreprocessGPU
+    for images, q_ids, t_ids, ids in loader:
+        if isinstance(images, PackedRaw):      # raw uint8 images (preprocess.RawRGB): resize / crop / normalise on the device,
+            if gpu_pre is None:                # one launch pair per loader batch
                 gpu_pre = ClipPreprocessGPU(int(getattr(getattr(model, "visual", None), "input_resolution", 224)), device)
-            images = torch.stack([gpu_pre(im) for im in images])
+            images = gpu_pre.batch(images)
         pend_i.append(images.to(device, non_blocking=True))
-        pend_q.append(tokenize_fn(queries).to(device, non_blocking=True))
-        pend_t.append(tokenize_fn(targets).to(device, non_blocking=True))
+        pend_q.append(q_ids.to(device, non_blocking=True))
+        pend_t.append(t_ids.to(device, non_blocking=True))
         pending += int(images.shape[0])
         uuids.extend(ids)
         if pending >= ENCODE_ITEMS:

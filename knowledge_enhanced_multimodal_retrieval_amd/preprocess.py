@@ -70,8 +70,75 @@ class ClipPreprocessGPU:
                                             C.c_void_p(engine._stream_ptr(self.device))), "preprocess_u8")
         return out
 
+    def batch(self, packed: "PackedRaw") -> torch.Tensor:
+        """A whole loader batch in one launch pair (``kemr_preprocess_u8_batch``): ``packed`` holds the uint8 images back
+        to back (:func:`pack_raw`); the bytes cross to the device in ONE copy (asynchronous when the buffer is pinned,
+        as the DataLoader's pin thread leaves it).  Returns float32 ``[B, 3, n_px, n_px]``, each image bit-identical to
+        ``self(image)`` and to the host transform."""
+        import ctypes as C
+        from . import _lib, engine
+        b = len(packed)
+        out = torch.empty((b, 3, self.n_px, self.n_px), dtype=torch.float32, device=self.device)
+        if b == 0:
+            return out
+        L = _lib.lib()
+        hs, ws, offs = packed.heights, packed.widths, packed.offsets          # int32 / int32 / int64 host arrays
+        need = int(L.kemr_preprocess_batch_workspace_bytes(C.c_void_p(hs.ctypes.data), C.c_void_p(ws.ctypes.data), b, self.n_px))
+        if need == 0:
+            raise RuntimeError(f"ClipPreprocessGPU.batch: unsupported image size in the batch -> {self.n_px}")
+        if self._ws is None or self._ws.numel() < need:
+            # grow-only, stream-ordered reuse: every user of the old buffer was queued on the same stream before this point
+            self._ws = torch.empty(max(need, 2 * (0 if self._ws is None else self._ws.numel())), dtype=torch.uint8, device=self.device)
+        data = packed.data if packed.data.device == self.device else packed.data.to(self.device, non_blocking=True)
+        with torch.cuda.device(self.device):
+            _lib.check(L.kemr_preprocess_u8_batch(C.c_void_p(data.data_ptr()), C.c_void_p(offs.ctypes.data),
+                                                  C.c_void_p(hs.ctypes.data), C.c_void_p(ws.ctypes.data), b, self.n_px,
+                                                  C.c_void_p(out.data_ptr()), C.c_void_p(self._ws.data_ptr()), self._ws.numel(),
+                                                  C.c_void_p(engine._stream_ptr(self.device))), "preprocess_u8_batch")
+        data.record_stream(torch.cuda.current_stream(self.device))
+        return out
+
     def __repr__(self):
         return f"ClipPreprocessGPU(n_px={self.n_px})"
+
+
+class PackedRaw:
+    """A loader batch of raw images as ONE flat uint8 tensor plus three small host arrays: what the batched preprocess
+    kernel reads.  ``data`` is a tensor so that the DataLoader's pin thread pins it; the sizes ride along as tensors too
+    and are viewed as numpy on use."""
+
+    def __init__(self, data: torch.Tensor, heights: torch.Tensor, widths: torch.Tensor):
+        self.data, self._h, self._w = data, heights, widths
+
+    def __len__(self):
+        return int(self._h.numel())
+
+    @property
+    def heights(self) -> np.ndarray:
+        return np.ascontiguousarray(self._h.numpy(), dtype=np.int32)
+
+    @property
+    def widths(self) -> np.ndarray:
+        return np.ascontiguousarray(self._w.numpy(), dtype=np.int32)
+
+    @property
+    def offsets(self) -> np.ndarray:
+        nbytes = self._h.numpy().astype(np.int64) * self._w.numpy().astype(np.int64) * 3
+        return np.ascontiguousarray(np.concatenate([[0], np.cumsum(nbytes)[:-1]]), dtype=np.int64)
+
+    def pin_memory(self, device=None):            # the DataLoader's pin thread calls this on custom batch types
+        return PackedRaw(self.data.pin_memory(), self._h, self._w)
+
+
+def pack_raw(images) -> PackedRaw:
+    """uint8 ``[H, W, 3]`` host tensors of any sizes -> :class:`PackedRaw` (one memcpy per image, in the loader worker)."""
+    for im in images:
+        if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3 or im.device.type != "cpu":
+            raise RuntimeError(f"pack_raw expects uint8 [H, W, 3] host tensors, got {im.dtype} {tuple(im.shape)} on {im.device}")
+    hs = torch.tensor([int(im.shape[0]) for im in images], dtype=torch.int32)
+    ws = torch.tensor([int(im.shape[1]) for im in images], dtype=torch.int32)
+    data = torch.cat([im.reshape(-1) for im in images]) if len(images) else torch.empty(0, dtype=torch.uint8)
+    return PackedRaw(data, hs, ws)
 
 
 class RawRGB:

@@ -51,6 +51,49 @@ def test_gpu_transform_is_bit_exact(device, h, w):
 
 
 @pytest.mark.gpu
+def test_gpu_batch_transform_is_bit_exact(device):
+    """One launch pair for a whole batch of mixed sizes (repeats share one filter table) == the host transform per image;
+    a second, larger batch reuses and grows the workspace; pinned and pageable sources give the same bytes."""
+    from PIL import Image
+    from knowledge_enhanced_multimodal_retrieval_amd.preprocess import pack_raw
+    pre = ClipPreprocessGPU(224, device)
+    host = ClipPreprocess(224)
+    for sizes in (SIZES[:5] + SIZES[:2], SIZES + [(224, 224)] * 3 + SIZES[::-1]):
+        arrs = [_image(h, w, 5 * h + w + i) for i, (h, w) in enumerate(sizes)]
+        want = torch.stack([host(Image.fromarray(a)) for a in arrs])
+        packed = pack_raw([torch.from_numpy(a) for a in arrs])
+        assert len(packed) == len(sizes) and packed.offsets[0] == 0 and packed.data.numel() == sum(h * w * 3 for h, w in sizes)
+        got = pre.batch(packed)
+        got_pinned = pre.batch(packed.pin_memory())
+        torch.cuda.synchronize()
+        assert torch.equal(got.cpu(), want) and torch.equal(got_pinned.cpu(), want)
+    assert pre.batch(pack_raw([])).shape == (0, 3, 224, 224)
+    with pytest.raises(RuntimeError, match="uint8"):
+        pack_raw([torch.zeros(4, 4, 3)])
+
+
+def test_collate_packs_raw_images_and_tokenizes_in_the_loader():
+    from knowledge_enhanced_multimodal_retrieval_amd import datasets
+    from knowledge_enhanced_multimodal_retrieval_amd.evaluators import default_tokenize
+    from knowledge_enhanced_multimodal_retrieval_amd.preprocess import PackedRaw
+    ds = datasets.SyntheticRawImageDataset(6, seed=3)
+    a, b = ds[4], ds[4]
+    assert a[0].dtype == torch.uint8 and a[0].shape[2] == 3 and torch.equal(a[0], b[0]) and a[1:] == b[1:]
+    images, q, t, ids = datasets.CollateAndTokenize(default_tokenize)([ds[i] for i in range(6)])
+    assert isinstance(images, PackedRaw) and len(images) == 6 and ids[5] == "synthetic-000005"
+    assert q.shape == (6, 77) and t.shape == (6, 77) and torch.equal(q, default_tokenize([ds[i][1] for i in range(6)]))
+    hs, ws, offs = images.heights, images.widths, images.offsets
+    for i in range(6):
+        im = ds[i][0]
+        assert (hs[i], ws[i]) == tuple(im.shape[:2])
+        assert torch.equal(images.data[offs[i]:offs[i] + im.numel()], im.reshape(-1))
+    # through a DataLoader with worker processes: same batches
+    from torch.utils.data import DataLoader
+    got = list(DataLoader(ds, batch_size=4, num_workers=2, collate_fn=datasets.CollateAndTokenize(default_tokenize)))
+    assert [len(g[0]) for g in got] == [4, 2] and torch.equal(got[0][1], q[:4]) and torch.equal(got[1][0].data[-10:], images.data[-10:])
+
+
+@pytest.mark.gpu
 def test_gpu_transform_other_resolution_and_errors(device):
     from PIL import Image
     arr = _image(500, 333, 7)
