@@ -11,6 +11,7 @@
 
 #include <array>
 #include <cmath>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -234,6 +235,30 @@ __global__ __launch_bounds__(256) void preprocess_v_batch_kernel(const PreImg* _
     out[2 * plane + gid] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)v2, 255.0f), m2), d2);
 }
 
+// Pinned staging for the per-batch descriptor blob: a ring of slots, each guarded by an event recorded after its copy; a slot
+// is reused only after that copy has finished (with 8 slots the wait only triggers when the host is 8 batches ahead).
+int staging_slot(size_t bytes, char** host, hipEvent_t* done) {
+    struct Slot { char* host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; };
+    static std::mutex mu;
+    static Slot ring[8];
+    static unsigned next = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    Slot& sl = ring[next++ % 8];
+    if (!sl.ev) KEMR_CHECK_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    if (sl.used) KEMR_CHECK_HIP(hipEventSynchronize(sl.ev));
+    if (sl.cap < bytes) {
+        if (sl.host) KEMR_CHECK_HIP(hipHostFree(sl.host));
+        sl.host = nullptr; sl.cap = 0;
+        const size_t cap = (size_t)round_up((int64_t)bytes * 2, 65536);
+        KEMR_CHECK_HIP(hipHostMalloc((void**)&sl.host, cap, hipHostMallocDefault));
+        sl.cap = cap;
+    }
+    sl.used = true;
+    *host = sl.host;
+    *done = sl.ev;
+    return KEMR_OK;
+}
+
 // host side of a batch: descriptors + the tables of the distinct sizes, and where everything lives in the workspace
 struct BatchLayout {
     std::vector<PreImg> desc;
@@ -297,9 +322,16 @@ extern "C" int kemr_preprocess_u8_batch(const unsigned char* packed_dev, const i
     if ((uintptr_t)workspace_dev % 256) KEMR_FAIL(KEMR_ERR_WORKSPACE, "preprocess batch: workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace_dev;
-    // descriptors and tables: pageable host memory is staged before hipMemcpyAsync returns, so the vectors may go out of scope
-    KEMR_CHECK_HIP(hipMemcpyAsync(ws, L.desc.data(), L.desc.size() * sizeof(PreImg), hipMemcpyHostToDevice, s));
-    if (!L.tables.empty()) KEMR_CHECK_HIP(hipMemcpyAsync(ws + L.tab_off, L.tables.data(), L.tables.size() * 4, hipMemcpyHostToDevice, s));
+    // descriptors + tables cross in ONE copy out of a pinned slot: a pageable source would make the "async" copy wait for
+    // the stream, i.e. for the encoders queued before it, and stall the loader thread behind the GPU
+    const size_t blob = L.tab_off + L.tables.size() * 4;
+    char* host = nullptr;
+    hipEvent_t done = nullptr;
+    KEMR_TRY(staging_slot(blob, &host, &done));
+    memcpy(host, L.desc.data(), L.desc.size() * sizeof(PreImg));
+    if (!L.tables.empty()) memcpy(host + L.tab_off, L.tables.data(), L.tables.size() * 4);
+    KEMR_CHECK_HIP(hipMemcpyAsync(ws, host, blob, hipMemcpyHostToDevice, s));
+    KEMR_CHECK_HIP(hipEventRecord(done, s));
     const int n = n_px;
     ProfScope prof(PROF_OTHER, s);
     hipLaunchKernelGGL(preprocess_h_batch_kernel, dim3((unsigned)(((size_t)L.max_rows * n + 255) / 256), (unsigned)batch), dim3(256), 0, s,

@@ -96,14 +96,27 @@ class SyntheticRawImageDataset(Dataset):
     def __len__(self):
         return self.n
 
+    _bases = {}
+
+    def _base(self, size):
+        """One seeded camera-like picture per size (coarse random field upsampled by repetition, plus fine noise), made once
+        per process: generating 600 KB of random pixels per item would make the benchmark measure numpy's generator."""
+        import numpy as np
+        key = (self.seed, size)
+        if key not in self._bases:
+            h, w = size
+            rng = np.random.default_rng(self.seed * 7919 + h * 4099 + w)
+            coarse = rng.integers(0, 256, size=((h + 15) // 16, (w + 15) // 16, 3), dtype=np.uint8)
+            image = np.repeat(np.repeat(coarse, 16, axis=0), 16, axis=1)[:h, :w]
+            self._bases[key] = np.ascontiguousarray(image ^ rng.integers(0, 32, size=(h, w, 1), dtype=np.uint8))
+        return self._bases[key]
+
     def __getitem__(self, idx):
         import numpy as np
         rng = np.random.default_rng(self.seed * 1_000_003 + idx)
-        h, w = self.SIZES[int(rng.integers(0, len(self.SIZES)))]
-        # smooth-ish content: a coarse random field upsampled by repetition + noise (resampling noise alone tests little)
-        coarse = rng.integers(0, 256, size=((h + 15) // 16, (w + 15) // 16, 3), dtype=np.uint8)
-        image = np.repeat(np.repeat(coarse, 16, axis=0), 16, axis=1)[:h, :w]
-        image = image ^ rng.integers(0, 32, size=(h, w, 1), dtype=np.uint8)
+        size = self.SIZES[int(rng.integers(0, len(self.SIZES)))]
+        # every item its own picture: the base rolled by an item-specific offset and XOR-ed with an item-specific byte
+        image = np.roll(self._base(size), int(rng.integers(0, size[1])), axis=1) ^ np.uint8(rng.integers(0, 64))
         _, query, target, uid = self._texts[idx]
         return torch.from_numpy(np.ascontiguousarray(image)), query, target, uid
 

@@ -60,6 +60,17 @@ def default_tokenize(texts: Sequence[str]) -> torch.Tensor:
 ENCODE_ITEMS = 255          # items per encoder call in encode_dataset (see there)
 
 
+def eval_loader(dataset, batch_size: int, seed: int, num_workers: int, tokenize_fn: Callable, pin: bool) -> DataLoader:
+    """The evaluation DataLoader (evaluator.py:96-105: no shuffle, seeded workers), with tokenisation and the packing of raw
+    images into one buffer moved INTO the loader (its worker processes when there are any); the pin thread pins both.
+    What is left on the consumer's thread per loader batch: three asynchronous copies and the kernel launches."""
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers, pin_memory=pin,
+                      collate_fn=CollateAndTokenize(tokenize_fn), worker_init_fn=seed_worker if num_workers else None,
+                      generator=g, prefetch_factor=4 if num_workers else None)
+
+
 @torch.no_grad()
 def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_workers: int = 0,
                    tokenize_fn: Optional[Callable] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, List[str]]:
@@ -67,14 +78,7 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
     model.eval()
     device = next(model.parameters()).device
     tokenize_fn = tokenize_fn or default_tokenize
-    g = torch.Generator()
-    g.manual_seed(seed)
-    # Tokenisation rides in the loader (in its worker processes when there are any), so does packing raw images into one
-    # buffer; the pin thread pins both.  What is left on this thread per loader batch: three async copies and the launches.
-    loader = DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers,
-                        pin_memory=device.type == "cuda", collate_fn=CollateAndTokenize(tokenize_fn),
-                        worker_init_fn=seed_worker if num_workers else None, generator=g,
-                        prefetch_factor=4 if num_workers else None, persistent_workers=False)
+    loader = eval_loader(dataset, batch_size, seed, num_workers, tokenize_fn, pin=device.type == "cuda")
     img, qry, tgt, uuids = [], [], [], []
     logger.info(f"Computing embeddings for {len(dataset)} samples...")
     # The loader's batch size is the host pipeline's business (the reference scripts pass 64); the encoders are fed

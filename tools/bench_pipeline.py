@@ -35,11 +35,12 @@ class Cached(torch.utils.data.Dataset):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--n", type=int, default=6120)
+    ap.add_argument("--n", type=int, default=43000)
     ap.add_argument("--workers", type=int, default=12)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--model", default="ViT-L/14")
     ap.add_argument("--cached", action="store_true")
+    ap.add_argument("--loader-only", action="store_true", help="iterate the loader without the GPU work: the host-side ceiling")
     ap.add_argument("--host-transform", action="store_true", help="the reference's arrangement: PIL transform in the loader")
     args = ap.parse_args()
     import clip
@@ -65,6 +66,13 @@ def main():
         warnings.simplefilter("ignore")
         evaluators.encode_dataset(model, Cached(ds, 510, 64), args.batch, 1, 0)          # warm: kernels, workspaces, plans
         torch.cuda.synchronize()
+        if args.loader_only:
+            t0 = time.perf_counter()
+            n = sum(len(b[3]) for b in evaluators.eval_loader(use, args.batch, 1, args.workers, evaluators.default_tokenize, True))
+            dt = time.perf_counter() - t0
+            print(json.dumps({"loader_only_items_per_s": round(3 * n / dt, 1), "seconds": round(dt, 3), "n": n,
+                              "workers": args.workers, "loader_batch": args.batch}))
+            return
         t0 = time.perf_counter()
         image, query, target, ids = evaluators.encode_dataset(model, use, args.batch, 1, args.workers)
         torch.cuda.synchronize()
