@@ -12,12 +12,17 @@ has exactly one exchange step:
 Ranks of a ground truth add two tiny reductions: the owner shard computes the ground-truth score
 (``kemr_pair_scores``; ``all_reduce(sum)`` with zeros elsewhere) and the per-shard ``ahead`` counts are summed.
 
+Step 3 is issued asynchronously (``search_async`` / ``search_many``): the candidate all-gather runs on RCCL's stream while
+the compute stream already encodes the NEXT query batch; the merge is queued when the result is asked for.  Every rank must
+bring the same number of query rows (a fused all-gather needs equal shapes; unequal ones hang or corrupt under RCCL): that
+is checked with one 2-element all-reduce per call and refused with a ValueError on every rank.
+
 The compute calls are taken from an ``ops`` namespace (default: the HIP-backed ``engine`` module) so that the
 collective plumbing can be exercised with gloo on CPU-only machines in tests; the product path always uses ``engine``.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -49,11 +54,51 @@ def all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
+def all_gather_rows_async(x: torch.Tensor, group=None):
+    """As :func:`all_gather_rows`, not waited for: returns (out, work); ``work.wait()`` orders the current stream after it."""
+    world, _ = _world(group)
+    if world == 1:
+        return x, None
+    x = x.contiguous()
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    return out, dist.all_gather_into_tensor(out, x, group=group, async_op=True)
+
+
+def require_equal_rows(n_local: int, device, group=None, what: str = "query rows") -> None:
+    """Refuse, on every rank, a call in which the ranks bring different row counts."""
+    world, rank = _world(group)
+    if world == 1:
+        return
+    t = torch.tensor([n_local, -n_local], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    hi, lo = int(t[0]), -int(t[1])
+    if hi != lo:
+        raise ValueError(f"sharded search: every rank must pass the same number of {what}; rank {rank} has {n_local}, "
+                         f"the group has between {lo} and {hi} (pad the last batch or split it evenly)")
+
+
+class PendingSearch:
+    """A search whose candidate exchange is in flight; ``result()`` queues the merge behind it."""
+
+    def __init__(self, merge: Callable, works, tensors):
+        self._merge, self._works, self._tensors, self._out = merge, works, tensors, None
+
+    def result(self):
+        if self._out is None:
+            for w in self._works:
+                if w is not None:
+                    w.wait()
+            self._out = self._merge(*self._tensors)
+            self._tensors = None
+        return self._out
+
+
 class ShardedGallery:
     """This rank's shard of the gallery, packed for the fused similarity kernel."""
 
     def __init__(self, local_parts: Sequence[torch.Tensor], n_total: int, precision: str = "fp32x3", group=None, ops=engine):
         self.group, self.ops = group, ops
+        self.check_rows = True        # one 2-element all-reduce + host read per call; a caller that guarantees equal batches may clear it
         self.world, self.rank = _world(group)
         self.n_total = n_total
         self.lo, self.hi = shard_bounds(n_total, self.world, self.rank)
@@ -64,28 +109,55 @@ class ShardedGallery:
         self.panel = ops.build_panel(list(local_parts), _lib.SIDE_GALLERY, self.terms) if self.hi > self.lo else None
 
     def _query_panel(self, local_query_parts, weights, row_gate):
+        if self.check_rows:
+            require_equal_rows(int(local_query_parts[0].shape[0]), local_query_parts[0].device, self.group)
         qs = [all_gather_rows(q, self.group) for q in local_query_parts]
         gates = None
         if row_gate is not None:
             gates = [None if g is None else all_gather_rows(g.reshape(-1, 1), self.group).reshape(-1) for g in row_gate]
         return self.ops.build_panel(qs, _lib.SIDE_QUERY, self.terms, part_scale=weights, row_scale=gates), qs[0].shape[0]
 
+    def _local_topk(self, qp, nq, k, dev, *rank_args):
+        if self.panel is not None:
+            return self.ops.sim_topk(qp, self.panel, k, self.lo, *rank_args)
+        return (torch.full((nq, k), float("-inf"), dtype=torch.float32, device=dev),
+                torch.full((nq, k), -1, dtype=torch.int32, device=dev))
+
+    def _exchange(self, s, i, k) -> PendingSearch:
+        """Candidates of all shards -> every rank, not waited for."""
+        if self.world == 1:
+            return PendingSearch(lambda a, b: (a, b), [], (s, i))
+        ss, w1 = all_gather_rows_async(s.unsqueeze(0), self.group)          # [world, Q, k]
+        ii, w2 = all_gather_rows_async(i.unsqueeze(0), self.group)
+        merge = lambda a, b: self.ops.topk_merge(a.permute(1, 0, 2).contiguous(), b.permute(1, 0, 2).contiguous(), k)
+        return PendingSearch(merge, [w1, w2], (ss, ii))
+
+    def search_async(self, local_query_parts: Sequence[torch.Tensor], weights: Optional[Sequence[float]] = None, k: int = 10,
+                     row_gate=None) -> PendingSearch:
+        """``search`` with the candidate exchange left in flight: encode the next query batch, then call ``result()``."""
+        qp, nq = self._query_panel(local_query_parts, weights, row_gate)
+        s, i = self._local_topk(qp, nq, k, local_query_parts[0].device)
+        return self._exchange(s, i, k)
+
     def search(self, local_query_parts: Sequence[torch.Tensor], weights: Optional[Sequence[float]] = None, k: int = 10,
                row_gate=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """Every rank passes its slice of the query batch (same row count on all ranks) and receives the merged
         top-k of the WHOLE batch against the WHOLE gallery: (scores [Q, k], global ids [Q, k])."""
-        qp, nq = self._query_panel(local_query_parts, weights, row_gate)
-        dev = local_query_parts[0].device
-        if self.panel is not None:
-            s, i = self.ops.sim_topk(qp, self.panel, k, self.lo)
-        else:
-            s = torch.full((nq, k), float("-inf"), dtype=torch.float32, device=dev)
-            i = torch.full((nq, k), -1, dtype=torch.int32, device=dev)
-        if self.world == 1:
-            return s, i
-        ss = all_gather_rows(s.unsqueeze(0), self.group)          # [world, Q, k]
-        ii = all_gather_rows(i.unsqueeze(0), self.group)
-        return self.ops.topk_merge(ss.permute(1, 0, 2).contiguous(), ii.permute(1, 0, 2).contiguous(), k)
+        return self.search_async(local_query_parts, weights, k, row_gate).result()
+
+    def search_many(self, batches: Iterable[Sequence[torch.Tensor]], weights: Optional[Sequence[float]] = None, k: int = 10
+                    ) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+        """A stream of query batches with one batch of lookahead.  ``batches`` is consumed lazily: if producing an element
+        encodes the texts (a generator around ``model.encode_text``), the encoder of batch b+1 is queued on the compute
+        stream while the candidate all-gather of batch b is still on the wire.  Yields the merged results in order."""
+        prev = None
+        for parts in batches:
+            cur = self.search_async(parts, weights, k)
+            if prev is not None:
+                yield prev.result()
+            prev = cur
+        if prev is not None:
+            yield prev.result()
 
     def ranks(self, local_query_parts: Sequence[torch.Tensor], local_gt: torch.Tensor,
               weights: Optional[Sequence[float]] = None, k: int = 10, row_gate=None
@@ -102,14 +174,9 @@ class ShardedGallery:
         if self.world > 1:
             dist.all_reduce(sgt, group=self.group)                 # exactly one rank contributed a non-zero per query
         ahead = torch.zeros(nq, dtype=torch.int32, device=dev)
-        if self.panel is not None:
-            s, i = self.ops.sim_topk(qp, self.panel, k, self.lo, gt, sgt, ahead)
-        else:
-            s = torch.full((nq, k), float("-inf"), dtype=torch.float32, device=dev)
-            i = torch.full((nq, k), -1, dtype=torch.int32, device=dev)
+        s, i = self._local_topk(qp, nq, k, dev, gt, sgt, ahead)
+        pending = self._exchange(s, i, k)
         if self.world > 1:
-            dist.all_reduce(ahead, group=self.group)
-            ss = all_gather_rows(s.unsqueeze(0), self.group)
-            ii = all_gather_rows(i.unsqueeze(0), self.group)
-            s, i = self.ops.topk_merge(ss.permute(1, 0, 2).contiguous(), ii.permute(1, 0, 2).contiguous(), k)
+            dist.all_reduce(ahead, group=self.group)               # rides while the candidates are gathered
+        s, i = pending.result()
         return ahead.long() + 1, s, i

@@ -83,6 +83,25 @@ def _worker(rank, world, port, n, nq, d, k, q_out):
     s, i = gal.search([ql, ql], weights=[0.3, 0.7], k=k)
     ranks, s2, i2 = gal.ranks([ql, ql], gt_l, weights=[0.3, 0.7], k=k)
     assert torch.equal(i, i2)
+    # a stream of query batches with the candidate exchange of batch b in flight while batch b+1 is produced: same answers
+    produced = []
+
+    def batches():
+        for h in range(2):
+            part = ql[h * (per // 2):(h + 1) * (per // 2)]
+            produced.append(h)
+            yield [part, part]
+    halves = list(gal.search_many(batches(), weights=[0.3, 0.7], k=k))
+    assert produced == [0, 1] and len(halves) == 2
+    for h, (hs, hi_) in enumerate(halves):       # rows of batch h: every rank's h-th half, in rank order
+        rows = torch.cat([torch.arange(r * per + h * (per // 2), r * per + (h + 1) * (per // 2)) for r in range(world)])
+        assert torch.equal(hi_, i[rows]) and torch.allclose(hs, s[rows], atol=1e-6)
+    # ranks that bring different numbers of query rows are refused on EVERY rank, before any data-sized collective
+    uneven = ql[:per - rank]
+    with pytest.raises(ValueError, match="same number of query rows"):
+        gal.search([uneven, uneven], weights=[0.3, 0.7], k=k)
+    with pytest.raises(ValueError, match="same number of query rows"):
+        gal.ranks([uneven, uneven], gt_l[:per - rank], weights=[0.3, 0.7], k=k)
     q_out.put((rank, s.numpy(), i.numpy(), ranks.numpy()))
     dist.barrier()
     dist.destroy_process_group()

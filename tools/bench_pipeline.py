@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--model", default="ViT-L/14")
     ap.add_argument("--cached", action="store_true")
     ap.add_argument("--loader-only", action="store_true", help="iterate the loader without the GPU work: the host-side ceiling")
+    ap.add_argument("--trace", action="store_true", help="host seconds spent inside the preprocess / encoder calls (no syncs added)")
     ap.add_argument("--host-transform", action="store_true", help="the reference's arrangement: PIL transform in the loader")
     args = ap.parse_args()
     import clip
@@ -73,8 +74,25 @@ def main():
             print(json.dumps({"loader_only_items_per_s": round(3 * n / dt, 1), "seconds": round(dt, 3), "n": n,
                               "workers": args.workers, "loader_batch": args.batch}))
             return
+        spent = {}
+        if args.trace:
+            def timed(owner, name, key):
+                fn = getattr(owner, name)
+
+                def wrapper(*a, **k):
+                    t = time.perf_counter()
+                    try:
+                        return fn(*a, **k)
+                    finally:
+                        spent[key] = spent.get(key, 0.0) + time.perf_counter() - t
+                setattr(owner, name, wrapper)
+            timed(evaluators.ClipPreprocessGPU, "batch", "preprocess.batch")
+            timed(model, "encode_image", "encode_image")
+            timed(model, "encode_text", "encode_text")
+            timed(torch, "cat", "torch.cat")
         t0 = time.perf_counter()
         image, query, target, ids = evaluators.encode_dataset(model, use, args.batch, 1, args.workers)
+        spent["until_loop_end"] = time.perf_counter() - t0
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     assert image.shape[0] == args.n and len(ids) == args.n and bool(torch.isfinite(image).all())
@@ -82,7 +100,8 @@ def main():
                       "n": args.n, "workers": args.workers, "loader_batch": args.batch, "model": args.model,
                       "source": "host transform in the loader" if args.host_transform else
                                 ("uint8 pool, device preprocessing" if args.cached else "uint8 generated per item, device preprocessing"),
-                      "precision": os.environ.get("KEMR_PRECISION", "default")}))
+                      "precision": os.environ.get("KEMR_PRECISION", "default"),
+                      **({"host_seconds": {k: round(v, 3) for k, v in spent.items()}} if args.trace else {})}))
 
 
 if __name__ == "__main__":
