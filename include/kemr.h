@@ -151,8 +151,14 @@ int kemr_panel_build(const float* const* parts_dev, const float* part_scale, con
  *   bonus_*: optional sparse additive bonuses (SPARQL hits, eval/fusion.py:22-206) in CSR over
  *            queries: bonus_rowptr int32 [nq+1], bonus_col int32 (GLOBAL ids, ascending within a row),
  *            bonus_val fp32.  Weighted fusion's alpha is folded into the query panel (part_scale).
- *   workspace >= kemr_sim_workspace_bytes(nq, ng, k) */
-size_t kemr_sim_workspace_bytes(int nq, int ng, int k);
+ *   Galleries of >= 8192 rows with >= 256 queries and no bonus list take their scores from the encoder GEMM's main loop as
+ *   well: thresholds from the exact top-k against a 1/12 sample of the gallery, one 256 x 256-tile pass that appends the
+ *   candidates above a query's threshold to its lists (the rank count rides along), one selection pass.  Same scores, same
+ *   order rule, same outputs bit for bit; lists that overflow re-run the slower kernel on the device (no host round trip).
+ *   workspace >= kemr_sim_workspace_bytes(nq, ng, kdim, k), 256-byte aligned */
+size_t kemr_sim_workspace_bytes(int nq, int ng, int64_t kdim, int k);
+/* tools / tests: 0 = never the candidate-list path, 1 = where it applies (default), 2 = lists, then the fallback forced */
+int kemr_set_sim_lists(int mode);
 int kemr_sim_topk(const void* q_panel_dev, int nq, const void* g_panel_dev, int ng, int64_t kdim,
                   int64_t gallery_offset, int k, float* top_scores_dev, int32_t* top_idx_dev,
                   const int32_t* gt_idx_dev, const float* gt_score_dev, int32_t* ahead_dev,

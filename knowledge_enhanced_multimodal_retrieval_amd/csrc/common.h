@@ -115,10 +115,23 @@ struct GemmParams {
     int32_t* sim_ahead;       // [nq] += candidates of this gallery ranked ahead of it
     int sim_ng, sim_gbase;    // valid gallery rows; global id of gallery row 0
     int sim_nchunks, sim_tpc; // gallery chunks per query tile, gallery tiles per chunk
+    // SIM == 2 (top-k candidates on top of the rank count): a lane whose 16 candidates of a query hold a score >= the query's
+    // threshold appends all 16 scores as one record to the (query, chunk) list
+    const float* simk_taud;   // [nq] next float below the threshold (s > taud  <=>  s >= threshold)
+    float* simk_scores;       // [nq][nchunks][cap][16]
+    int32_t* simk_base;       // [nq][nchunks][cap] global id of a record's first candidate (element j: + (j >> 2) * 16 + (j & 3))
+    int32_t* simk_count;      // [nq][nchunks] records appended (clamped to cap)
+    int32_t* simk_flag;       // |= 1 when a list overflowed: the caller's exact fallback runs
+    int simk_cap;
 };
 extern int g_gemm_dbg;
 extern int g_gemm_order;
 int gemm_read_stamps(unsigned* host_out, int n_words);
+struct SimkPlan { int nchunks, tpc, cap; size_t scores_bytes, base_bytes, count_bytes; };
+int gemm256u_simk_plan(int nq, int ng, int kdim, double hits_per_query, SimkPlan* plan, bool* ok);
+int launch_gemm256u_simk(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, long long gallery_offset,
+                         const int32_t* gt_idx, const float* gt_score, int32_t* ahead, const float* taud, const SimkPlan& plan,
+                         float* rec_scores, int32_t* rec_base, int32_t* rec_count, int32_t* flag, hipStream_t stream);
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);      // picks the tile variant
 int launch_gemm256(const GemmParams& p, int epi, hipStream_t stream);   // gemm256.hip: 256x256x64, 8 waves, counted vmcnt
 int launch_gemm256p(const GemmParams& p, int epi, hipStream_t stream);  // gemm256p.hip: persistent, async epilogue (bf16-store epilogues)

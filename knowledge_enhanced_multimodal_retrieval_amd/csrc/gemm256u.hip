@@ -139,7 +139,7 @@ constexpr int GEMM256U_MAX_TILES_PER_WG = 62;         // the tile table is one l
 // ahead of the query's ground truth (reference metrics.py:13-76: Recall@K / MRR need nothing else).  One workgroup = one
 // 256-query tile x one chunk of gallery tiles (blockIdx = q_tile * nchunks + chunk); same MFMA operand roles and k order as
 // sim_kernel / pair_scores_kernel (sim.hip), so the scores are theirs bit for bit.
-template <int EPI, bool FP8, bool DBG = false, bool SIM = false>
+template <int EPI, bool FP8, bool DBG = false, int SIM = 0>
 __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmParams p) {
     constexpr int ES = FP8 ? 1 : 2;          // operand element size
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     int ntl = (ntiles - (int)blockIdx.x + G - 1) / G;                // tiles of this workgroup, <= GEMM256U_MAX_TILES_PER_WG (host)
     int t_row = 0, t_col = 0;
     int sim_tb = 0;                                                  // SIM: first gallery tile of this workgroup's chunk
-    if constexpr (SIM) {
+    if constexpr (SIM != 0) {
         const int qt = (int)blockIdx.x / p.sim_nchunks, chunk = (int)blockIdx.x - qt * p.sim_nchunks;
         sim_tb = chunk * p.sim_tpc;
         const int te = min(sim_tb + p.sim_tpc, tiles_n);
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     // With the W1 half of K-tile 0 of a tile: that tile's bias (wave 0).  The bias rides with the LAST piece in front of a
     // wait-free stretch, so that nobody waits for it straight after issuing it.
     auto stage_bias = [&]() {
-        if constexpr (SIM) return;
+        if constexpr (SIM != 0) return;
         if (__builtin_expect(tw == nt, 0)) {
             if (wid == 0) {
                 const unsigned boff = ((unsigned)__builtin_amdgcn_readlane(v_bcol, seqw) + lane * 4) * 4u;
@@ -297,6 +297,20 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     const int b_off = 2 * PHALF + (wc >> 1) * PHALF + ((wc & 1) * 64 + lrow) * 128;
 
     if (!p.bias && tid < 128) *(float4*)(smem + PBIAS + tid * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (SIM == 2) {
+        // per-query constants and the list counters of the workgroup's 256 queries live in the (otherwise unused) epilogue
+        // area: {ground-truth score, next float below it, ground-truth id, next float below the top-k threshold}, counter
+        if (tid < 256) {
+            const int q = t_row_u + tid;
+            const bool ok = q < p.M;
+            const float g = (ok && p.sim_sgt) ? p.sim_sgt[q] : INFINITY;
+            const unsigned u = __float_as_uint(g);
+            const float gd = __uint_as_float((u << 1) == 0u ? 0x80000001u : ((u >> 31) ? u + 1u : u - 1u));
+            const int gi = (ok && p.sim_gt) ? p.sim_gt[q] : -1;
+            *(float4*)(smem + PEPI + tid * 16) = make_float4(g, gd, __int_as_float(gi), ok ? p.simk_taud[q] : INFINITY);
+            *(int*)(smem + PEPI + 4096 + tid * 4) = 0;
+        }
+    }
     // prologue: K-tile 0 complete, both W halves of K-tile 1 in flight (nt >= 2, so all of it belongs to the first tile)
     stage_w(ow, stage_lds + 2 * PHALF);
     stage_w(ow1, stage_lds + 3 * PHALF);
@@ -518,9 +532,14 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     // SIM: per-lane state of the 8 queries a lane holds (rows wr * 128 + mi * 16 + lrow of the query tile)
     float sgt[8], sgd[8];                          // ground-truth score, and the next float below it (s > sgd  <=>  s >= sgt)
     int gtid[8], cnt[8];
-    if constexpr (SIM) {
+    int k_ovf = 0;
+    if constexpr (SIM != 0) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) { b4[ni] = u32x4{0u, 0u, 0u, 0u}; asm volatile("" : "+v"(b4[ni])); }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) cnt[mi] = 0;
+    }
+    if constexpr (SIM == 1) {
         int il = lane;
         asm volatile("" : "+v"(il));
 #pragma unroll
@@ -532,11 +551,10 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             const unsigned u = __float_as_uint(sgt[mi]);
             // next float below (finite input, NaN excluded by the host): -0 / +0 -> the smallest negative number
             sgd[mi] = __uint_as_float((u << 1) == 0u ? 0x80000001u : ((u >> 31) ? u + 1u : u - 1u));
-            cnt[mi] = 0;
         }
     }
     for (int seq = 0; seq < ntl; ++seq) {
-        if constexpr (!FP8 && !SIM) {
+        if constexpr (!FP8 && SIM == 0) {
             // The tile's bias came in with its first W0 piece, which the wait + barrier that closed the previous K-tile (or the
             // prologue) cover; a lane's accumulators cover columns wc * 64 + ni * 16 + lq * 4 .. + 3.
             int il = lane;
@@ -550,7 +568,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
         for (int t = 1; t < nt; ++t) ktile(std::false_type{});
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // asm MFMA result -> VALU read (>= 12 wait states)
 
-        if constexpr (SIM) {
+        if constexpr (SIM != 0) {
             // ---- scan: acc[mi][ni][r] = score(query wr*128 + mi*16 + lrow, candidate wc*64 + ni*16 + lq*4 + r of this gallery tile).
             // Order rule of the whole path: a candidate ranks ahead of the ground truth iff  s > sgt  or  (s == sgt and id < gt).
             // All of a lane's 16 candidates lie on one side of gt unless gt falls into the lane's 52-id window, so one threshold per
@@ -561,10 +579,21 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             const int cb = p.sim_gbase + ((sim_tb + seq) << 8) + wc * 64 + (sl >> 4) * 4;       // global id of the lane's first candidate
             const bool ragged = ((sim_tb + seq + 1) << 8) > p.sim_ng;                            // wave-uniform: some candidates do not exist
             const int n_end = p.sim_gbase + p.sim_ng;
+            unsigned hitmask = 0;
+            int slot[8];
+            const float4* const qs = (const float4*)(smem + PEPI) + wr * 128 + (sl & 15);      // SIM == 2: the lane's query rows, + mi * 16
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
-                const int d = gtid[mi] - cb;
-                const float thr = d > 51 ? sgd[mi] : sgt[mi];
+                float g_s, g_d, taud = 0.f;
+                int g_i;
+                if constexpr (SIM == 2) {
+                    const float4 st = qs[mi * 16];
+                    g_s = st.x; g_d = st.y; g_i = __float_as_int(st.z); taud = st.w;
+                } else {
+                    g_s = sgt[mi]; g_d = sgd[mi]; g_i = gtid[mi];
+                }
+                const int d = g_i - cb;
+                const float thr = d > 51 ? g_d : g_s;
                 const bool mixed = (unsigned)d <= 51u;
                 int c = 0;
 #pragma unroll
@@ -579,12 +608,46 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
                         for (int r = 0; r < 4; ++r) {
                             const int e = ni * 16 + r;
                             const float sc = acc[mi][ni][r];
-                            const bool ahead = (cb + e < n_end) && e != d && (sc > sgt[mi] || (sc == sgt[mi] && e < d));
+                            const bool ahead = (cb + e < n_end) && e != d && (sc > g_s || (sc == g_s && e < d));
                             ce += ahead ? 1 : 0;
                         }
                     c = (mixed || ragged) ? ce : c;
                 }
                 cnt[mi] += c;
+                if constexpr (SIM == 2) {
+                    // top-k candidates: one test per (lane, query) on the maximum of the lane's 16 scores; a hit takes a slot
+                    // of the query's list (LDS counter: the 4 x 4 lanes that share a query row race for it)
+                    float m = acc[mi][0][0];
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[mi][ni][r]);
+                    slot[mi] = 0;
+                    if (m > taud) {
+                        hitmask |= 1u << mi;
+                        slot[mi] = atomicAdd((int*)(smem + PEPI + 4096) + wr * 128 + mi * 16 + (sl & 15), 1);
+                    }
+                }
+            }
+            if constexpr (SIM == 2) {
+                if (__builtin_amdgcn_ballot_w64(hitmask != 0u) != 0) {
+                    const int chunk = (int)blockIdx.x - ((int)blockIdx.x / p.sim_nchunks) * p.sim_nchunks;
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) {
+                        if ((hitmask >> mi) & 1u) {
+                            const int q = t_row_u + wr * 128 + mi * 16 + (sl & 15);
+                            if (slot[mi] < p.simk_cap) {
+                                const size_t rec = ((size_t)q * p.sim_nchunks + chunk) * p.simk_cap + slot[mi];
+                                f32x4* dst = (f32x4*)(p.simk_scores + rec * 16);
+#pragma unroll
+                                for (int ni = 0; ni < 4; ++ni) dst[ni] = acc[mi][ni];
+                                p.simk_base[rec] = cb;
+                            } else {
+                                k_ovf = 1;
+                            }
+                        }
+                    }
+                }
             }
         } else {
             // ---- epilogue (lane constants behind an opaque copy of `lane`: recomputed here, not kept across the K loop)
@@ -674,13 +737,18 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
 #undef KEMR_GLDS
 #undef KEMR_STREAM_STEP1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the streams' pieces behind the last K-tile land in LDS: before the exit
-    if constexpr (SIM) {
+    if constexpr (SIM != 0) {
         int fl = lane;
         asm volatile("" : "+v"(fl));
+        if (SIM == 1 || p.sim_gt) {
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int q = t_row_u + wr * 128 + mi * 16 + (fl & 15);
-            if (q < p.M && cnt[mi]) atomicAdd(p.sim_ahead + q, cnt[mi]);
+            for (int mi = 0; mi < 8; ++mi) {
+                const int q = t_row_u + wr * 128 + mi * 16 + (fl & 15);
+                if (q < p.M && cnt[mi]) atomicAdd(p.sim_ahead + q, cnt[mi]);
+            }
+        }
+        if constexpr (SIM == 2) {
+            if (k_ovf) atomicOr(p.simk_flag, 1);
         }
     }
     if constexpr (DBG) {
@@ -698,6 +766,16 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
         }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();      // pairs with the extra barrier the wr == 1 half took at the start
+    if constexpr (SIM == 2) {
+        // both halves are level again: one more barrier and every wave's list appends are in the counters
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid < 256 && t_row_u + tid < p.M) {
+            const int chunk = (int)blockIdx.x - ((int)blockIdx.x / p.sim_nchunks) * p.sim_nchunks;
+            const int n = *(volatile int*)(smem + PEPI + 4096 + tid * 4);
+            p.simk_count[(size_t)(t_row_u + tid) * p.sim_nchunks + chunk] = min(n, p.simk_cap);
+        }
+    }
 }
 
 static int gemm256u_num_cu(int* out) {
@@ -763,18 +841,14 @@ int gemm_read_stamps(unsigned* host_out, int n_words) {
     return KEMR_OK;
 }
 
-// Rank-only similarity pass (kemr_sim_topk with k == 0 and no bonus list).  Panels must be allocated with their row count
-// rounded up to 256 (include/kemr.h).  *used = false: the shape is outside this kernel (the caller falls back to sim_kernel).
-int launch_gemm256u_simrank(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, long long gallery_offset,
-                            const int32_t* gt_idx, const float* gt_score, int32_t* ahead, hipStream_t stream, bool* used) {
-    *used = false;
+// chunks of the gallery per query tile: as few rounds of workgroups over the CUs as possible, counting half a tile of
+// prologue per workgroup; a chunk is at most the tile table's size.  Returns 0 when the shape is outside the kernel.
+static int sim_chunking(int nq, int ng, int kdim, long long gallery_offset, int* tpc_out) {
     int num_cu = 0;
-    KEMR_TRY(gemm256u_num_cu(&num_cu));
+    if (gemm256u_num_cu(&num_cu) != KEMR_OK) return 0;
     const int q_tiles = (nq + 255) / 256, g_tiles = (ng + 255) / 256;
-    if (kdim % 64 != 0 || kdim < 128 || gallery_offset + ng > 0x7fffffffLL) return KEMR_OK;
-    if ((long)q_tiles * 256 * kdim * 2 >= (1L << 32) || (long)g_tiles * 256 * kdim * 2 >= (1L << 32)) return KEMR_OK;
-    // chunks of the gallery per query tile: as few rounds of workgroups over the CUs as possible, counting half a tile of
-    // prologue per workgroup; a chunk is at most the tile table's size
+    if (kdim % 64 != 0 || kdim < 128 || gallery_offset + ng > 0x7fffffffLL) return 0;
+    if ((long)q_tiles * 256 * kdim * 2 >= (1L << 32) || (long)g_tiles * 256 * kdim * 2 >= (1L << 32)) return 0;
     int best_c = 0;
     double best = 1e30;
     for (int c = (g_tiles + GEMM256U_MAX_TILES_PER_WG - 1) / GEMM256U_MAX_TILES_PER_WG; c <= g_tiles && c <= 512; ++c) {
@@ -783,13 +857,14 @@ int launch_gemm256u_simrank(const bf16_t* q_panel, int nq, const bf16_t* g_panel
         const double cost = (double)((items + num_cu - 1) / num_cu) * (tpc + 0.5);
         if (cost < best - 1e-9) { best = cost; best_c = nch; }
     }
-    if (best_c <= 0) return KEMR_OK;
-    GemmParams p{};
-    p.A = q_panel; p.lda = kdim; p.W = g_panel; p.ldw = kdim; p.M = nq; p.N = g_tiles * 256; p.K = kdim;
-    p.sim_gt = gt_idx; p.sim_sgt = gt_score; p.sim_ahead = ahead; p.sim_ng = ng; p.sim_gbase = (int)gallery_offset;
-    p.sim_tpc = (g_tiles + best_c - 1) / best_c;
-    p.sim_nchunks = (g_tiles + p.sim_tpc - 1) / p.sim_tpc;
-    auto kern = gemm256u_bf16_nt_kernel<EPI_BIAS_BF16, false, false, true>;
+    if (best_c <= 0) return 0;
+    *tpc_out = (g_tiles + best_c - 1) / best_c;
+    return (g_tiles + *tpc_out - 1) / *tpc_out;
+}
+
+template <int SIM>
+static int launch_sim_mode(const GemmParams& p, int q_tiles, hipStream_t stream) {
+    auto kern = gemm256u_bf16_nt_kernel<EPI_BIAS_BF16, false, false, SIM>;
     static int attr_dev = -1;
     int dev = 0;
     KEMR_CHECK_HIP(hipGetDevice(&dev));
@@ -800,8 +875,59 @@ int launch_gemm256u_simrank(const bf16_t* q_panel, int nq, const bf16_t* g_panel
     ProfScope prof(PROF_SIM, stream);
     hipLaunchKernelGGL(kern, dim3(q_tiles * p.sim_nchunks), dim3(512), PSMEM, stream, p);
     KEMR_CHECK_LAUNCH("gemm256u_bf16_nt_kernel<sim>");
+    return KEMR_OK;
+}
+
+// Rank-only similarity pass (kemr_sim_topk with k == 0 and no bonus list).  Panels must be allocated with their row count
+// rounded up to 256 (include/kemr.h).  *used = false: the shape is outside this kernel (the caller falls back to sim_kernel).
+int launch_gemm256u_simrank(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, long long gallery_offset,
+                            const int32_t* gt_idx, const float* gt_score, int32_t* ahead, hipStream_t stream, bool* used) {
+    *used = false;
+    int tpc = 0;
+    const int nch = sim_chunking(nq, ng, kdim, gallery_offset, &tpc);
+    if (nch <= 0) return KEMR_OK;
+    const int q_tiles = (nq + 255) / 256, g_tiles = (ng + 255) / 256;
+    GemmParams p{};
+    p.A = q_panel; p.lda = kdim; p.W = g_panel; p.ldw = kdim; p.M = nq; p.N = g_tiles * 256; p.K = kdim;
+    p.sim_gt = gt_idx; p.sim_sgt = gt_score; p.sim_ahead = ahead; p.sim_ng = ng; p.sim_gbase = (int)gallery_offset;
+    p.sim_tpc = tpc; p.sim_nchunks = nch;
+    KEMR_TRY(launch_sim_mode<1>(p, q_tiles, stream));
     *used = true;
     return KEMR_OK;
+}
+
+// Top-k candidate pass (SIM == 2).  hits_per_query: the expected number of (lane, query) records per query over the whole
+// gallery (the caller derives it from how its thresholds were chosen); a list holds 3x the mean per chunk + 8, rounded up
+// to a power of two.  *ok = false: the shape is outside the kernel.
+int gemm256u_simk_plan(int nq, int ng, int kdim, double hits_per_query, SimkPlan* plan, bool* ok) {
+    *ok = false;
+    int tpc = 0;
+    const int nch = sim_chunking(nq, ng, kdim, 0, &tpc);
+    if (nch <= 0) return KEMR_OK;
+    int cap = 16;
+    const double want = 3.0 * hits_per_query / nch + 8.0;
+    while (cap < want && cap < 4096) cap *= 2;
+    plan->nchunks = nch; plan->tpc = tpc; plan->cap = cap;
+    const size_t lists = (size_t)nq * nch;
+    plan->scores_bytes = lists * cap * 64;
+    plan->base_bytes = lists * cap * 4;
+    plan->count_bytes = (lists * 4 + 255) / 256 * 256;
+    *ok = true;
+    return KEMR_OK;
+}
+
+int launch_gemm256u_simk(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, long long gallery_offset,
+                         const int32_t* gt_idx, const float* gt_score, int32_t* ahead, const float* taud, const SimkPlan& plan,
+                         float* rec_scores, int32_t* rec_base, int32_t* rec_count, int32_t* flag, hipStream_t stream) {
+    if (gallery_offset + ng > 0x7fffffffLL) KEMR_FAIL(KEMR_ERR_INVALID, "simk: candidate ids exceed int32");
+    const int q_tiles = (nq + 255) / 256, g_tiles = (ng + 255) / 256;
+    GemmParams p{};
+    p.A = q_panel; p.lda = kdim; p.W = g_panel; p.ldw = kdim; p.M = nq; p.N = g_tiles * 256; p.K = kdim;
+    p.sim_gt = gt_idx; p.sim_sgt = gt_score; p.sim_ahead = ahead; p.sim_ng = ng; p.sim_gbase = (int)gallery_offset;
+    p.sim_tpc = plan.tpc; p.sim_nchunks = plan.nchunks;
+    p.simk_taud = taud; p.simk_scores = rec_scores; p.simk_base = rec_base; p.simk_count = rec_count; p.simk_flag = flag;
+    p.simk_cap = plan.cap;
+    return launch_sim_mode<2>(p, q_tiles, stream);
 }
 
 // C must have ceil256(M) rows: rows in [M, ceil256(M)) are written (with values computed from A's pad rows).

@@ -83,6 +83,7 @@ struct SimParams {
     float* dense;
     long long ld_dense;
     int nchunks, tiles_per_chunk, g_tiles;
+    const int32_t* run_if;   // non-null: the launch is the exact fallback of the candidate-list path and exits unless *run_if != 0
 };
 
 template <int KMAX>
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(256) void sim_kernel(const SimParams p) {
     // of LDS instead of 130 lets two workgroups share a CU, so one scans while the other is in its MFMA loop.
     float* sS = (float*)smem;
 
+    if (p.run_if && *p.run_if == 0) return;              // uniform: before any barrier
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = wid >> 1, wcn = wid & 1;              // wave's query half / candidate half
@@ -276,7 +278,8 @@ __global__ __launch_bounds__(256) void sim_kernel(const SimParams p) {
 // one wave per query; k rounds of "best element strictly after the previous pick" over nlists*k entries
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ in_s, const int32_t* __restrict__ in_i,
                                                          int nq, int total, int k, float* __restrict__ out_s,
-                                                         int32_t* __restrict__ out_i) {
+                                                         int32_t* __restrict__ out_i, const int32_t* __restrict__ run_if) {
+    if (run_if && *run_if == 0) return;
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
@@ -365,12 +368,12 @@ __global__ __launch_bounds__(256) void topk_merge_block_kernel(const float* __re
 }
 
 static int launch_topk_merge(const float* in_s, const int32_t* in_i, int nq, int total, int k, float* out_s, int32_t* out_i,
-                             hipStream_t stream) {
-    if (nq <= 64 && total > 256 && total <= 256 * MERGE_EPT) {
+                             hipStream_t stream, const int32_t* run_if = nullptr) {
+    if (!run_if && nq <= 64 && total > 256 && total <= 256 * MERGE_EPT) {
         hipLaunchKernelGGL(topk_merge_block_kernel, dim3(nq), dim3(256), 0, stream, in_s, in_i, total, k, out_s, out_i);
         KEMR_CHECK_LAUNCH("topk_merge_block_kernel");
     } else {
-        hipLaunchKernelGGL(topk_merge_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, in_s, in_i, nq, total, k, out_s, out_i);
+        hipLaunchKernelGGL(topk_merge_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, in_s, in_i, nq, total, k, out_s, out_i, run_if);
         KEMR_CHECK_LAUNCH("topk_merge_kernel");
     }
     return KEMR_OK;
@@ -434,6 +437,99 @@ extern "C" int kemr_panel_build(const float* const* parts_dev, const float* part
     return KEMR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ top-k by candidate lists
+// Large galleries: the scores come out of the persistent GEMM's K loop (gemm256u.hip, SIM == 2) instead of sim_kernel.
+//   1. thresholds: the exact top-k of every query against a strided SAMPLE of the gallery (sim_kernel on 1/12 of the rows).
+//      The k-th score of the sample is a lower bound of the k-th score of the gallery, so every member of the true top-k
+//      scores >= it -- whatever the data, the lists below contain the answer.
+//   2. the 256 x 256-tile pass over the whole gallery: a lane whose 16 candidates of a query hold a score >= the query's
+//      threshold appends them as one record to the (query, chunk) list; the ground-truth rank count rides in the same pass.
+//   3. one wave per query picks the k best of its lists' entries with the path's order rule (score desc, id asc).
+// A list that overflows (thresholds far too low: e.g. thousands of equal scores) raises a flag, and the sim_kernel path
+// then runs after all: its launches are always queued and exit at once while the flag is clear (no host round trip).
+__global__ __launch_bounds__(256) void sample_rows_kernel(const bf16_t* __restrict__ G, int ng, int kdim, int m,
+                                                          bf16_t* __restrict__ out) {
+    const int per_row = kdim >> 3;                                   // 16-byte pieces
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)m * per_row) return;
+    const int j = (int)(i / per_row), c = (int)(i - (long long)j * per_row);
+    const long long src = (long long)j * ng / m;                     // strided sample, distinct rows (ng >= m)
+    ((uint4*)out)[i] = ((const uint4*)(G + (size_t)src * kdim))[c];
+}
+
+__global__ __launch_bounds__(256) void simk_threshold_kernel(const float* __restrict__ sample_top, int nq, int k,
+                                                             float* __restrict__ taud, int32_t* __restrict__ flag) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q == 0) *flag = 0;
+    if (q >= nq) return;
+    const unsigned u = __float_as_uint(sample_top[(size_t)q * k + (k - 1)]);
+    // next float below the threshold (s > taud  <=>  s >= threshold); -inf (a sample with fewer than k rows) stays -inf
+    taud[q] = u == 0xff800000u ? -INFINITY : __uint_as_float((u << 1) == 0u ? 0x80000001u : ((u >> 31) ? u + 1u : u - 1u));
+}
+
+constexpr int SIMK_SELECT = 1024;       // entries >= threshold one query may bring to the selection (more: the flag)
+__global__ __launch_bounds__(256) void simk_select_kernel(const float* __restrict__ rec_scores, const int32_t* __restrict__ rec_base,
+                                                          const int32_t* __restrict__ rec_count, int nchunks, int cap,
+                                                          const float* __restrict__ taud, int nq, int k, int n_end,
+                                                          float* __restrict__ out_s, int32_t* __restrict__ out_i,
+                                                          int32_t* __restrict__ flag) {
+    __shared__ float ls[4][SIMK_SELECT];
+    __shared__ int li[4][SIMK_SELECT];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + w;
+    if (q >= nq) return;                                             // no workgroup barrier below
+    const float td = taud[q];
+    int n = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const int cnt = rec_count[(size_t)q * nchunks + c];
+        const size_t rec0 = ((size_t)q * nchunks + c) * cap;
+        for (int r0 = 0; r0 < cnt; r0 += 4) {                        // 4 records x 16 entries per step
+            const int rec = r0 + (lane >> 4), el = lane & 15;
+            const bool ok = rec < cnt;
+            const float sc = ok ? rec_scores[(rec0 + rec) * 16 + el] : 0.f;
+            const int id = ok ? rec_base[rec0 + rec] + (el >> 2) * 16 + (el & 3) : -1;
+            const bool keep = ok && sc > td && id < n_end;           // id >= n_end: the gallery panel's zero pad rows
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+            const int pos = n + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            if (keep && pos < SIMK_SELECT) { ls[w][pos] = sc; li[w][pos] = id; }
+            n += __builtin_popcountll(mask);
+        }
+    }
+    if (n > SIMK_SELECT) {
+        if (lane == 0) atomicOr(flag, 1);
+        n = SIMK_SELECT;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float ps = INFINITY;
+    int pi = -1;
+    for (int o = 0; o < k; ++o) {
+        float bs = -INFINITY;
+        int bi = -1;
+        for (int e = lane; e < n; e += 64) {
+            const float es = ls[w][e];
+            const int ei = li[w][e];
+            const bool after_prev = (o == 0) || ranks_before(ps, pi, es, ei);
+            if (after_prev && (bi < 0 || ranks_before(es, ei, bs, bi))) { bs = es; bi = ei; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float os = __shfl_xor(bs, off);
+            const int oi = __shfl_xor(bi, off);
+            if (oi >= 0 && (bi < 0 || ranks_before(os, oi, bs, bi))) { bs = os; bi = oi; }
+        }
+        if (lane == 0) { out_s[(size_t)q * k + o] = bi >= 0 ? bs : -INFINITY; out_i[(size_t)q * k + o] = bi; }
+        if (bi < 0) {
+            for (int r = o + 1 + lane; r < k; r += 64) { out_s[(size_t)q * k + r] = -INFINITY; out_i[(size_t)q * k + r] = -1; }
+            break;
+        }
+        ps = bs;
+        pi = bi;
+    }
+}
+
+static int g_sim_lists = 1;
+
 static int sim_chunks(int nq, int ng, int* tiles_per_chunk) {
     const int q_tiles = (nq + ST - 1) / ST, g_tiles = (ng + ST - 1) / ST;
     int want = (768 + q_tiles - 1) / q_tiles;           // aim for >= 3 workgroups per CU
@@ -444,11 +540,46 @@ static int sim_chunks(int nq, int ng, int* tiles_per_chunk) {
     return (g_tiles + tpc - 1) / tpc;
 }
 
-extern "C" size_t kemr_sim_workspace_bytes(int nq, int ng, int k) {
-    if (nq <= 0 || ng <= 0 || k <= 0) return 0;     // k == 0: rank only, no partial lists
+static size_t sim_lists_bytes(int nq, int ng, int k) {
     int tpc;
     const int nchunks = sim_chunks(nq, ng, &tpc);
     return (size_t)round_up((int64_t)nq * nchunks * k * 8, 256);
+}
+
+// workspace of the candidate-list path (behind the sim_kernel path's own lists, which its fallback needs)
+struct SimkLayout {
+    bool on = false;
+    int m = 0;                     // sampled gallery rows
+    SimkPlan plan{};
+    size_t off_sample = 0, off_lists_a = 0, off_top_a = 0, off_taud = 0, off_flag = 0, off_count = 0, off_base = 0, off_scores = 0, bytes = 0;
+};
+
+static SimkLayout simk_layout(int nq, int ng, int64_t kdim, int k) {
+    SimkLayout L;
+    L.bytes = sim_lists_bytes(nq, ng, k);
+    if (k < 1 || nq < 256 || ng < 8192 || kdim % 64 != 0 || kdim < 128 || kdim > 65536) return L;
+    int m = (int)round_up((int64_t)ng / 12, 256);
+    m = m < 1024 ? 1024 : (m > 8192 ? 8192 : m);
+    bool ok = false;
+    if (gemm256u_simk_plan(nq, ng, (int)kdim, (double)k * ng / m, &L.plan, &ok) != KEMR_OK || !ok) return L;
+    size_t at = L.bytes;
+    auto take = [&](size_t b) { const size_t o = at; at += (size_t)round_up((int64_t)b, 256); return o; };
+    L.off_sample = take((size_t)m * kdim * 2);
+    L.off_lists_a = take(sim_lists_bytes(nq, m, k));
+    L.off_top_a = take((size_t)nq * k * 8);
+    L.off_taud = take((size_t)nq * 4);
+    L.off_flag = take(4);
+    L.off_count = take(L.plan.count_bytes);
+    L.off_base = take(L.plan.base_bytes);
+    L.off_scores = take(L.plan.scores_bytes);
+    if (at > ((size_t)8 << 30)) return L;          // lists beyond 8 GiB: not this path
+    L.on = true; L.m = m; L.bytes = at;
+    return L;
+}
+
+extern "C" size_t kemr_sim_workspace_bytes(int nq, int ng, int64_t kdim, int k) {
+    if (nq <= 0 || ng <= 0 || k <= 0) return 0;     // k == 0: rank only, no partial lists
+    return simk_layout(nq, ng, kdim, k).bytes;
 }
 
 template <int KMAX, bool DENSE>
@@ -491,8 +622,11 @@ extern "C" int kemr_sim_topk(const void* q_panel_dev, int nq, const void* g_pane
     if ((bonus_rowptr_dev != nullptr) != (bonus_col_dev != nullptr) || (bonus_rowptr_dev != nullptr) != (bonus_val_dev != nullptr))
         KEMR_FAIL(KEMR_ERR_INVALID, "sim_topk: bonus CSR arrays must be given together");
     if (gallery_offset < 0 || gallery_offset + ng > 0x7fffffffLL) KEMR_FAIL(KEMR_ERR_INVALID, "sim_topk: candidate ids exceed int32");
-    const size_t need = kemr_sim_workspace_bytes(nq, ng, k);
+    const bool lists_ok = !bonus_rowptr_dev && k > 0;
+    const SimkLayout L = lists_ok ? simk_layout(nq, ng, kdim, k) : SimkLayout{};
+    const size_t need = k > 0 ? (L.on ? L.bytes : sim_lists_bytes(nq, ng, k)) : 0;
     if (k > 0 && (!workspace_dev || workspace_bytes < need)) KEMR_FAIL(KEMR_ERR_WORKSPACE, "sim_topk: workspace %zu < %zu bytes", workspace_bytes, need);
+    if (k > 0 && (uintptr_t)workspace_dev % 256) KEMR_FAIL(KEMR_ERR_WORKSPACE, "sim_topk: workspace must be 256-byte aligned");
     SimParams p{};
     p.Q = (const bf16_t*)q_panel_dev; p.G = (const bf16_t*)g_panel_dev; p.nq = nq; p.ng = ng; p.kdim = (int)kdim;
     p.goff = gallery_offset; p.k = k;
@@ -508,10 +642,54 @@ extern "C" int kemr_sim_topk(const void* q_panel_dev, int nq, const void* g_pane
         KEMR_TRY(launch_gemm256u_simrank(p.Q, nq, p.G, ng, (int)kdim, gallery_offset, gt_idx_dev, gt_score_dev, ahead_dev, s, &used));
         if (used) return KEMR_OK;
     }
+    if (L.on && g_sim_lists) {                // top-k (and ranks) through candidate lists: see above
+        char* ws = (char*)workspace_dev;
+        bf16_t* sample = (bf16_t*)(ws + L.off_sample);
+        float* top_a = (float*)(ws + L.off_top_a);
+        float* taud = (float*)(ws + L.off_taud);
+        int32_t* flag = (int32_t*)(ws + L.off_flag);
+        {
+            const long long pieces = (long long)L.m * (kdim >> 3);
+            hipLaunchKernelGGL(sample_rows_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, p.G, ng, (int)kdim, L.m, sample);
+            KEMR_CHECK_LAUNCH("sample_rows_kernel");
+        }
+        SimParams a{};
+        a.Q = p.Q; a.G = sample; a.nq = nq; a.ng = L.m; a.kdim = (int)kdim; a.goff = 0; a.k = k;
+        a.nchunks = sim_chunks(nq, L.m, &a.tiles_per_chunk);
+        a.g_tiles = (L.m + ST - 1) / ST;
+        a.part_scores = (float*)(ws + L.off_lists_a);
+        a.part_idx = (int32_t*)(ws + L.off_lists_a + (size_t)nq * a.nchunks * k * 4);
+        if (k <= 10) KEMR_TRY((launch_sim<10, false>(a, s)));
+        else KEMR_TRY((launch_sim<32, false>(a, s)));
+        KEMR_TRY(launch_topk_merge(a.part_scores, a.part_idx, nq, a.nchunks * k, k, top_a, (int32_t*)(top_a + (size_t)nq * k), s));
+        hipLaunchKernelGGL(simk_threshold_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, top_a, nq, k, taud, flag);
+        KEMR_CHECK_LAUNCH("simk_threshold_kernel");
+        KEMR_TRY(launch_gemm256u_simk(p.Q, nq, p.G, ng, (int)kdim, gallery_offset, gt_idx_dev, gt_score_dev, ahead_dev, taud, L.plan,
+                                      (float*)(ws + L.off_scores), (int32_t*)(ws + L.off_base), (int32_t*)(ws + L.off_count), flag, s));
+        hipLaunchKernelGGL(simk_select_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, (const float*)(ws + L.off_scores),
+                           (const int32_t*)(ws + L.off_base), (const int32_t*)(ws + L.off_count), L.plan.nchunks, L.plan.cap, taud, nq, k,
+                           (int)(gallery_offset + ng), top_scores_dev, top_idx_dev, flag);
+        KEMR_CHECK_LAUNCH("simk_select_kernel");
+        // the exact fallback, queued unconditionally: both kernels exit at once unless a list overflowed.  The ranks are
+        // already complete (the count does not depend on the lists), so the fallback runs without a ground truth.
+        p.gt_idx = nullptr; p.gt_score = nullptr; p.ahead = nullptr;
+        p.run_if = g_sim_lists == 2 ? nullptr : flag;
+        if (k <= 10) KEMR_TRY((launch_sim<10, false>(p, s)));
+        else KEMR_TRY((launch_sim<32, false>(p, s)));
+        return launch_topk_merge(p.part_scores, p.part_idx, nq, p.nchunks * k, k, top_scores_dev, top_idx_dev, s, p.run_if);
+    }
     if (k <= 10) KEMR_TRY((launch_sim<10, false>(p, s)));
     else KEMR_TRY((launch_sim<32, false>(p, s)));
     if (k == 0) return KEMR_OK;
     return launch_topk_merge(p.part_scores, p.part_idx, nq, p.nchunks * k, k, top_scores_dev, top_idx_dev, s);
+}
+
+// tools / tests: 0 = always sim_kernel, 1 = candidate lists where they apply (default), 2 = lists AND the fallback forced to
+// run after them (its result overwrites theirs: exercises the overflow route)
+extern "C" int kemr_set_sim_lists(int mode) {
+    if (mode < 0 || mode > 2) KEMR_FAIL(KEMR_ERR_INVALID, "set_sim_lists: mode %d not in 0..2", mode);
+    g_sim_lists = mode;
+    return KEMR_OK;
 }
 
 extern "C" int kemr_scores_dense(const void* q_panel_dev, int nq, const void* g_panel_dev, int ng, int64_t kdim,

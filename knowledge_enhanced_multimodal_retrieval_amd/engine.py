@@ -211,7 +211,7 @@ def sim_topk(qp: Panel, gp: Panel, k: int, gallery_offset: int = 0,
         return top_s, top_i
     if ng == 0:
         return top_s.fill_(float("-inf")), top_i.fill_(-1)
-    ws = torch.empty(max(int(L.kemr_sim_workspace_bytes(nq, ng, k)), 256), dtype=torch.uint8, device=dev)
+    ws = torch.empty(max(int(L.kemr_sim_workspace_bytes(nq, ng, qp.kdim, k)), 256), dtype=torch.uint8, device=dev)
     if gt_idx is not None:
         if gt_score is None or ahead is None:
             raise RuntimeError("sim_topk: gt_idx needs gt_score and ahead")

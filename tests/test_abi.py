@@ -83,7 +83,7 @@ def test_host_side_shape_checks():
     lib = _lib.lib()
     assert lib.kemr_panel_kdim(768, 1, 1) == 768 and lib.kemr_panel_kdim(768, 2, 3) == 4608
     assert lib.kemr_panel_kdim(100, 1, 3) == 384 and lib.kemr_panel_kdim(768, 1, 2) == -1
-    assert lib.kemr_sim_workspace_bytes(1024, 43000, 10) > 0 and lib.kemr_sim_workspace_bytes(0, 5, 10) == 0
+    assert lib.kemr_sim_workspace_bytes(1024, 43000, 768, 10) > 0 and lib.kemr_sim_workspace_bytes(0, 5, 768, 10) == 0
     assert lib.kemr_sim_topk(None, 1, None, 1, 64, 0, 10, None, None, None, None, None, None, None, None, None, 0, None) == -1
     assert lib.kemr_op_gemm(None, None, None, None, 1, 128, 64, 0, None) == -1
     assert lib.kemr_profile_end(None, None, 0) == -2

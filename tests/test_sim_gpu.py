@@ -265,6 +265,74 @@ def test_rank_only_fast_path_matches_counting_rule(device, nq, ng, d, terms, off
         assert torch.equal(acc2, want)
 
 
+def _lists_mode(mode):
+    _lib.check(_lib.lib().kemr_set_sim_lists(mode), "set_sim_lists")
+
+
+@pytest.mark.parametrize("nq,ng,d,terms,off,k", [(300, 9000, 128, 1, 0, 10), (257, 16000, 128, 1, 5, 5), (600, 20001, 192, 3, 1000, 32),
+                                                 (256, 8192, 64, 1, 0, 1), (1024, 43000, 768, 1, 0, 10)])
+def test_topk_by_candidate_lists_is_the_kernel_path_bit_for_bit(device, nq, ng, d, terms, off, k):
+    """>= 8192 gallery rows and >= 256 queries: thresholds from a 1/12 sample, candidate lists out of the 256 x 256-tile pass,
+    selection (sim.hip).  Scores, ids and rank counts must equal (a) sim_kernel's on the same panels and (b) a stable
+    descending sort of the dense scores of the same arithmetic -- with exact ties around the ground truth, a ragged last tile,
+    a gallery offset; (c) the forced fallback route gives the same answer again."""
+    g = torch.Generator().manual_seed(nq * 7 + ng)
+    gal = torch.nn.functional.normalize(torch.randn(ng, d, generator=g), dim=-1)
+    gt = torch.randint(0, ng, (nq,), generator=g)
+    for q in range(0, nq, 3):
+        t = int(gt[q])
+        if t >= 2:
+            gal[t - 2] = gal[t]
+        if t + 3 < ng:
+            gal[t + 3] = gal[t]
+    qry = torch.nn.functional.normalize(gal[gt] + 0.5 * torch.randn(nq, d, generator=g), dim=-1)
+    gal, qry, gt = gal.to(device), qry.to(device), gt.to(device)
+    qp = engine.build_panel([qry], _lib.SIDE_QUERY, terms)
+    gp = engine.build_panel([gal], _lib.SIDE_GALLERY, terms)
+    gtg = (gt + off).int()
+    sgt = engine.pair_scores(qp, gp, torch.arange(nq, device=device).int(), gt.int())
+    out = {}
+    try:
+        for mode in (0, 1, 2):
+            _lists_mode(mode)
+            ahead = torch.zeros(nq, dtype=torch.int32, device=device)
+            s_, i_ = engine.sim_topk(qp, gp, k, off, gtg, sgt, ahead)
+            s2, i2 = engine.sim_topk(qp, gp, k, off)                       # no ground truth: same lists
+            assert torch.equal(s_, s2) and torch.equal(i_, i2)
+            out[mode] = (s_, i_, ahead)
+    finally:
+        _lists_mode(1)
+    for mode in (1, 2):
+        for a, b in zip(out[0], out[mode]):
+            assert torch.equal(a, b), mode
+    if nq * ng <= 2e7:
+        S = engine.scores_dense(qp, gp)
+        order = torch.sort(S, dim=1, descending=True, stable=True)
+        assert torch.equal(order.values[:, :k], out[1][0]) and torch.equal(order.indices[:, :k].int() + off, out[1][1])
+        ids = torch.arange(ng, device=device)[None, :]
+        want = (((S > sgt[:, None]) | ((S == sgt[:, None]) & (ids < gt[:, None]))) & (ids != gt[:, None])).sum(1).int()
+        assert torch.equal(out[1][2], want)
+
+
+def test_candidate_lists_overflow_falls_back_on_the_device(device):
+    """Thousands of equal scores above every threshold (a gallery of copies of three rows): the lists overflow, the flag is
+    raised on the device and the always-queued sim_kernel launches produce the answer: ids in ascending order among ties."""
+    nq, ng, d, k = 256, 9000, 64, 10
+    g = torch.Generator().manual_seed(5)
+    base = torch.nn.functional.normalize(torch.randn(3, d, generator=g), dim=-1)
+    gal = base[torch.arange(ng) % 3].to(device)
+    qry = torch.nn.functional.normalize(base[torch.arange(nq) % 3] + 0.1 * torch.randn(nq, d, generator=g), dim=-1).to(device)
+    qp = engine.build_panel([qry], _lib.SIDE_QUERY, 1)
+    gp = engine.build_panel([gal], _lib.SIDE_GALLERY, 1)
+    gt = (torch.arange(nq) % 3 + 3 * 7).int().to(device)
+    sgt = engine.pair_scores(qp, gp, torch.arange(nq, device=device).int(), gt)
+    ahead = torch.zeros(nq, dtype=torch.int32, device=device)
+    top_s, top_i = engine.sim_topk(qp, gp, k, 0, gt, sgt, ahead)
+    want_i = (torch.arange(nq)[:, None] % 3 + 3 * torch.arange(k)[None, :]).int().to(device)
+    assert torch.equal(top_i, want_i) and torch.equal(ahead, torch.full_like(ahead, 7))
+    assert bool((top_s == top_s[:, :1]).all())
+
+
 @pytest.mark.parametrize("terms", [1, 3])
 def test_full_gallery_fused_two_part_properties(device, terms):
     """BASELINE configs[2] at the 43k gallery: fused T2I + T2T scoring = ONE contraction over [w_i * image | w_t * target]
