@@ -159,6 +159,9 @@ int kemr_panel_build(const float* const* parts_dev, const float* part_scale, con
 size_t kemr_sim_workspace_bytes(int nq, int ng, int64_t kdim, int k);
 /* tools / tests: 0 = never the candidate-list path, 1 = where it applies (default), 2 = lists, then the fallback forced */
 int kemr_set_sim_lists(int mode);
+/* tools: flag / longest list / capacity / chunks / sampled rows / records per query left in `workspace` by the last
+ * kemr_sim_topk of these sizes on the candidate-list route (all zero when the route does not apply; synchronises) */
+int kemr_debug_sim_lists(const void* workspace_dev, int nq, int ng, int64_t kdim, int k, int32_t* out6);
 int kemr_sim_topk(const void* q_panel_dev, int nq, const void* g_panel_dev, int ng, int64_t kdim,
                   int64_t gallery_offset, int k, float* top_scores_dev, int32_t* top_idx_dev,
                   const int32_t* gt_idx_dev, const float* gt_score_dev, int32_t* ahead_dev,

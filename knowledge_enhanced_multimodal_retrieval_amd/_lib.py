@@ -54,6 +54,7 @@ SIGNATURES = {
     "kemr_panel_build": (_i, [C.POINTER(_vp), C.POINTER(_f), C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp]),
     "kemr_sim_workspace_bytes": (_sz, [_i, _i, _i64, _i]),
     "kemr_set_sim_lists": (_i, [_i]),
+    "kemr_debug_sim_lists": (_i, [_vp, _i, _i, _i64, _i, _vp]),
     "kemr_sim_topk": (_i, [_vp, _i, _vp, _i, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kemr_pair_scores": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _vp, _vp]),
     "kemr_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -574,8 +574,27 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             // All of a lane's 16 candidates lie on one side of gt unless gt falls into the lane's 52-id window, so one threshold per
             // query does (sgd for "ids below gt": >= as >); the rare mixed window and a gallery's ragged last tile are recounted
             // element by element.
+            stamp(8);
             int sl = lane;
             asm volatile("" : "+v"(sl));
+            if constexpr (SIM == 3) {
+                // group maxima: the best score of every query among the 64 candidates of this wave's column block (a lane's 16,
+                // then the 4 lanes that share the query row) -> simk_scores[query][tile * 4 + wc]
+                const int groups = (p.N >> 8) * 4, grp = (sim_tb + seq) * 4 + wc;
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) {
+                    float m = acc[mi][0][0];
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[mi][ni][r]);
+                    m = fmaxf(m, __shfl_xor(m, 16));
+                    m = fmaxf(m, __shfl_xor(m, 32));
+                    const int q = t_row_u + wr * 128 + mi * 16 + (sl & 15);
+                    if (sl < 16 && q < p.M) p.simk_scores[(size_t)q * groups + grp] = m;
+                }
+                continue;
+            }
             const int cb = p.sim_gbase + ((sim_tb + seq) << 8) + wc * 64 + (sl >> 4) * 4;       // global id of the lane's first candidate
             const bool ragged = ((sim_tb + seq + 1) << 8) > p.sim_ng;                            // wave-uniform: some candidates do not exist
             const int n_end = p.sim_gbase + p.sim_ng;
@@ -596,6 +615,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
                 const float thr = d > 51 ? g_d : g_s;
                 const bool mixed = (unsigned)d <= 51u;
                 int c = 0;
+                if (SIM == 1 || p.sim_gt) {           // (uniform) a search without a ground truth has nothing to count
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -612,6 +632,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
                             ce += ahead ? 1 : 0;
                         }
                     c = (mixed || ragged) ? ce : c;
+                }
                 }
                 cnt[mi] += c;
                 if constexpr (SIM == 2) {
@@ -740,7 +761,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     if constexpr (SIM != 0) {
         int fl = lane;
         asm volatile("" : "+v"(fl));
-        if (SIM == 1 || p.sim_gt) {
+        if (SIM == 1 || (SIM == 2 && p.sim_gt)) {
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
                 const int q = t_row_u + wr * 128 + mi * 16 + (fl & 15);
@@ -862,9 +883,9 @@ static int sim_chunking(int nq, int ng, int kdim, long long gallery_offset, int*
     return (g_tiles + *tpc_out - 1) / *tpc_out;
 }
 
-template <int SIM>
-static int launch_sim_mode(const GemmParams& p, int q_tiles, hipStream_t stream) {
-    auto kern = gemm256u_bf16_nt_kernel<EPI_BIAS_BF16, false, false, SIM>;
+template <int SIM, bool DBG>
+static int launch_sim_mode_a(const GemmParams& p, int q_tiles, hipStream_t stream) {
+    auto kern = gemm256u_bf16_nt_kernel<EPI_BIAS_BF16, false, DBG, SIM>;
     static int attr_dev = -1;
     int dev = 0;
     KEMR_CHECK_HIP(hipGetDevice(&dev));
@@ -872,10 +893,23 @@ static int launch_sim_mode(const GemmParams& p, int q_tiles, hipStream_t stream)
         KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PSMEM));
         attr_dev = dev;
     }
+    GemmParams q = p;
+    if (DBG) {
+        q.dbg = g_gemm_dbg;
+        KEMR_CHECK_HIP(hipGetSymbolAddress((void**)&q.stamps, HIP_SYMBOL(g_gemm_stamp_buf)));
+    }
     ProfScope prof(PROF_SIM, stream);
-    hipLaunchKernelGGL(kern, dim3(q_tiles * p.sim_nchunks), dim3(512), PSMEM, stream, p);
+    hipLaunchKernelGGL(kern, dim3(q_tiles * p.sim_nchunks), dim3(512), PSMEM, stream, q);
     KEMR_CHECK_LAUNCH("gemm256u_bf16_nt_kernel<sim>");
     return KEMR_OK;
+}
+
+template <int SIM>
+static int launch_sim_mode(const GemmParams& p, int q_tiles, hipStream_t stream) {
+    if constexpr (SIM != 3) {
+        if (g_gemm_dbg & (64 | 128)) return launch_sim_mode_a<SIM, true>(p, q_tiles, stream);      // tools: stamped instantiation
+    }
+    return launch_sim_mode_a<SIM, false>(p, q_tiles, stream);
 }
 
 // Rank-only similarity pass (kemr_sim_topk with k == 0 and no bonus list).  Panels must be allocated with their row count
@@ -904,8 +938,11 @@ int gemm256u_simk_plan(int nq, int ng, int kdim, double hits_per_query, SimkPlan
     int tpc = 0;
     const int nch = sim_chunking(nq, ng, kdim, 0, &tpc);
     if (nch <= 0) return KEMR_OK;
+    // Records per (query, chunk) list: Poisson around a Gamma(k)-distributed mean (the threshold is an order statistic of a
+    // sample), whose upper tail is long: over 10^5 lists a capacity of 3x the mean overflowed in every second call (measured,
+    // round 2), 5x + 16 is beyond 10^-10 per list
     int cap = 16;
-    const double want = 3.0 * hits_per_query / nch + 8.0;
+    const double want = 5.0 * hits_per_query / nch + 16.0;
     while (cap < want && cap < 4096) cap *= 2;
     plan->nchunks = nch; plan->tpc = tpc; plan->cap = cap;
     const size_t lists = (size_t)nq * nch;
@@ -928,6 +965,24 @@ int launch_gemm256u_simk(const bf16_t* q_panel, int nq, const bf16_t* g_panel, i
     p.simk_taud = taud; p.simk_scores = rec_scores; p.simk_base = rec_base; p.simk_count = rec_count; p.simk_flag = flag;
     p.simk_cap = plan.cap;
     return launch_sim_mode<2>(p, q_tiles, stream);
+}
+
+// Group maxima (SIM == 3): out[nq][ceil256(ng) / 64] = the best score of every query within each block of 64 gallery rows.
+// g_panel must be padded to whole 256-row tiles with REAL rows (the caller samples a multiple of 256).
+int launch_gemm256u_simgmax(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, float* out, hipStream_t stream,
+                            bool* used) {
+    *used = false;
+    if (ng % 256 != 0) KEMR_FAIL(KEMR_ERR_INVALID, "simgmax: %d gallery rows are not whole tiles", ng);
+    int tpc = 0;
+    const int nch = sim_chunking(nq, ng, kdim, 0, &tpc);
+    if (nch <= 0) return KEMR_OK;
+    GemmParams p{};
+    p.A = q_panel; p.lda = kdim; p.W = g_panel; p.ldw = kdim; p.M = nq; p.N = ng; p.K = kdim;
+    p.sim_ng = ng; p.sim_tpc = tpc; p.sim_nchunks = nch;
+    p.simk_scores = out;
+    KEMR_TRY(launch_sim_mode<3>(p, (nq + 255) / 256, stream));
+    *used = true;
+    return KEMR_OK;
 }
 
 // C must have ceil256(M) rows: rows in [M, ceil256(M)) are written (with values computed from A's pad rows).

@@ -14,6 +14,7 @@
 // Per (query, gallery chunk) partial lists go to the workspace and are merged by topk_merge_kernel, the same
 // kernel that merges per-GPU shards.  Order rule everywhere: higher score first, then lower candidate id.
 #include "common.h"
+#include <vector>
 
 namespace kemr {
 
@@ -439,9 +440,10 @@ extern "C" int kemr_panel_build(const float* const* parts_dev, const float* part
 
 // ------------------------------------------------------------------------------------------------ top-k by candidate lists
 // Large galleries: the scores come out of the persistent GEMM's K loop (gemm256u.hip, SIM == 2) instead of sim_kernel.
-//   1. thresholds: the exact top-k of every query against a strided SAMPLE of the gallery (sim_kernel on 1/12 of the rows).
-//      The k-th score of the sample is a lower bound of the k-th score of the gallery, so every member of the true top-k
-//      scores >= it -- whatever the data, the lists below contain the answer.
+//   1. thresholds: a strided SAMPLE of the gallery (1/12 of the rows) goes through the same K loop, which keeps the best
+//      score of every query within each block of 64 sampled rows (SIM == 3); the k-th largest of these block maxima is the
+//      score of k distinct gallery items, hence a lower bound of the k-th score of the gallery: every member of the true
+//      top-k scores >= it -- whatever the data, the lists below contain the answer.
 //   2. the 256 x 256-tile pass over the whole gallery: a lane whose 16 candidates of a query hold a score >= the query's
 //      threshold appends them as one record to the (query, chunk) list; the ground-truth rank count rides in the same pass.
 //   3. one wave per query picks the k best of its lists' entries with the path's order rule (score desc, id asc).
@@ -457,17 +459,34 @@ __global__ __launch_bounds__(256) void sample_rows_kernel(const bf16_t* __restri
     ((uint4*)out)[i] = ((const uint4*)(G + (size_t)src * kdim))[c];
 }
 
-__global__ __launch_bounds__(256) void simk_threshold_kernel(const float* __restrict__ sample_top, int nq, int k,
+// one wave per query: k-th largest of its <= 128 block maxima (k rounds of "wave maximum, remove one instance")
+__global__ __launch_bounds__(256) void simk_threshold_kernel(const float* __restrict__ gmax, int nq, int groups, int k,
                                                              float* __restrict__ taud, int32_t* __restrict__ flag) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q == 0) *flag = 0;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *flag = 0;
     if (q >= nq) return;
-    const unsigned u = __float_as_uint(sample_top[(size_t)q * k + (k - 1)]);
-    // next float below the threshold (s > taud  <=>  s >= threshold); -inf (a sample with fewer than k rows) stays -inf
-    taud[q] = u == 0xff800000u ? -INFINITY : __uint_as_float((u << 1) == 0u ? 0x80000001u : ((u >> 31) ? u + 1u : u - 1u));
+    float v0 = lane < groups ? gmax[(size_t)q * groups + lane] : -INFINITY;
+    float v1 = lane + 64 < groups ? gmax[(size_t)q * groups + lane + 64] : -INFINITY;
+    float m = -INFINITY;
+    for (int o = 0; o < k; ++o) {
+        m = fmaxf(v0, v1);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        const unsigned long long owners = __builtin_amdgcn_ballot_w64(v0 == m || v1 == m);
+        if (lane == __builtin_ctzll(owners)) {
+            if (v0 == m) v0 = -INFINITY;
+            else v1 = -INFINITY;
+        }
+    }
+    if (lane == 0) {
+        const unsigned u = __float_as_uint(m);
+        // next float below the threshold (s > taud  <=>  s >= threshold); fewer than k blocks: -inf, everything is listed
+        taud[q] = u == 0xff800000u ? -INFINITY : __uint_as_float((u << 1) == 0u ? 0x80000001u : ((u >> 31) ? u + 1u : u - 1u));
+    }
 }
 
-constexpr int SIMK_SELECT = 1024;       // entries >= threshold one query may bring to the selection (more: the flag)
+constexpr int SIMK_SELECT = 512;        // entries >= threshold one query may bring to the selection (more: the flag)
 __global__ __launch_bounds__(256) void simk_select_kernel(const float* __restrict__ rec_scores, const int32_t* __restrict__ rec_base,
                                                           const int32_t* __restrict__ rec_count, int nchunks, int cap,
                                                           const float* __restrict__ taud, int nq, int k, int n_end,
@@ -480,19 +499,27 @@ __global__ __launch_bounds__(256) void simk_select_kernel(const float* __restric
     if (q >= nq) return;                                             // no workgroup barrier below
     const float td = taud[q];
     int n = 0;
-    for (int c = 0; c < nchunks; ++c) {
-        const int cnt = rec_count[(size_t)q * nchunks + c];
-        const size_t rec0 = ((size_t)q * nchunks + c) * cap;
-        for (int r0 = 0; r0 < cnt; r0 += 4) {                        // 4 records x 16 entries per step
-            const int rec = r0 + (lane >> 4), el = lane & 15;
-            const bool ok = rec < cnt;
-            const float sc = ok ? rec_scores[(rec0 + rec) * 16 + el] : 0.f;
-            const int id = ok ? rec_base[rec0 + rec] + (el >> 2) * 16 + (el & 3) : -1;
-            const bool keep = ok && sc > td && id < n_end;           // id >= n_end: the gallery panel's zero pad rows
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
-            const int pos = n + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            if (keep && pos < SIMK_SELECT) { ls[w][pos] = sc; li[w][pos] = id; }
-            n += __builtin_popcountll(mask);
+    for (int c0 = 0; c0 < nchunks; c0 += 64) {
+        const int mine = c0 + lane < nchunks ? rec_count[(size_t)q * nchunks + c0 + lane] : 0;      // 64 list lengths at once
+        const int span = min(64, nchunks - c0);
+        for (int cc = 0; cc < span; ++cc) {
+            const int cnt = __shfl(mine, cc);
+            const size_t rec0 = ((size_t)q * nchunks + c0 + cc) * cap;
+            for (int r0 = 0; r0 < cnt; r0 += 16) {                   // 16 records per step: a lane takes a quarter (4 scores) of one
+                const int rec = r0 + (lane >> 2), ni = lane & 3;
+                const bool ok = rec < cnt;
+                const float4 sc = ok ? ((const float4*)rec_scores)[(rec0 + rec) * 4 + ni] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int id0 = ok ? rec_base[rec0 + rec] + ni * 16 : 0;
+                const float v[4] = {sc.x, sc.y, sc.z, sc.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool keep = ok && v[r] > td && id0 + r < n_end;       // id >= n_end: the gallery panel's zero pad rows
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+                    const int pos = n + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                    if (keep && pos < SIMK_SELECT) { ls[w][pos] = v[r]; li[w][pos] = id0 + r; }
+                    n += __builtin_popcountll(mask);
+                }
+            }
         }
     }
     if (n > SIMK_SELECT) {
@@ -551,7 +578,7 @@ struct SimkLayout {
     bool on = false;
     int m = 0;                     // sampled gallery rows
     SimkPlan plan{};
-    size_t off_sample = 0, off_lists_a = 0, off_top_a = 0, off_taud = 0, off_flag = 0, off_count = 0, off_base = 0, off_scores = 0, bytes = 0;
+    size_t off_sample = 0, off_gmax = 0, off_taud = 0, off_flag = 0, off_count = 0, off_base = 0, off_scores = 0, bytes = 0;
 };
 
 static SimkLayout simk_layout(int nq, int ng, int64_t kdim, int k) {
@@ -559,14 +586,16 @@ static SimkLayout simk_layout(int nq, int ng, int64_t kdim, int k) {
     L.bytes = sim_lists_bytes(nq, ng, k);
     if (k < 1 || nq < 256 || ng < 8192 || kdim % 64 != 0 || kdim < 128 || kdim > 65536) return L;
     int m = (int)round_up((int64_t)ng / 12, 256);
+    const int m_min = (int)round_up(64 * (int64_t)k, 256);                     // k block maxima need k blocks of 64 rows
     m = m < 1024 ? 1024 : (m > 8192 ? 8192 : m);
+    m = m < m_min ? m_min : m;
     bool ok = false;
-    if (gemm256u_simk_plan(nq, ng, (int)kdim, (double)k * ng / m, &L.plan, &ok) != KEMR_OK || !ok) return L;
+    // expected records per query: the k-th block maximum sits a little below the k-th item of the sample (measured: 1.1x)
+    if (gemm256u_simk_plan(nq, ng, (int)kdim, 1.15 * k * ng / m, &L.plan, &ok) != KEMR_OK || !ok) return L;
     size_t at = L.bytes;
     auto take = [&](size_t b) { const size_t o = at; at += (size_t)round_up((int64_t)b, 256); return o; };
     L.off_sample = take((size_t)m * kdim * 2);
-    L.off_lists_a = take(sim_lists_bytes(nq, m, k));
-    L.off_top_a = take((size_t)nq * k * 8);
+    L.off_gmax = take((size_t)nq * (m / 64) * 4);
     L.off_taud = take((size_t)nq * 4);
     L.off_flag = take(4);
     L.off_count = take(L.plan.count_bytes);
@@ -645,7 +674,7 @@ extern "C" int kemr_sim_topk(const void* q_panel_dev, int nq, const void* g_pane
     if (L.on && g_sim_lists) {                // top-k (and ranks) through candidate lists: see above
         char* ws = (char*)workspace_dev;
         bf16_t* sample = (bf16_t*)(ws + L.off_sample);
-        float* top_a = (float*)(ws + L.off_top_a);
+        float* gmax = (float*)(ws + L.off_gmax);
         float* taud = (float*)(ws + L.off_taud);
         int32_t* flag = (int32_t*)(ws + L.off_flag);
         {
@@ -653,16 +682,10 @@ extern "C" int kemr_sim_topk(const void* q_panel_dev, int nq, const void* g_pane
             hipLaunchKernelGGL(sample_rows_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, p.G, ng, (int)kdim, L.m, sample);
             KEMR_CHECK_LAUNCH("sample_rows_kernel");
         }
-        SimParams a{};
-        a.Q = p.Q; a.G = sample; a.nq = nq; a.ng = L.m; a.kdim = (int)kdim; a.goff = 0; a.k = k;
-        a.nchunks = sim_chunks(nq, L.m, &a.tiles_per_chunk);
-        a.g_tiles = (L.m + ST - 1) / ST;
-        a.part_scores = (float*)(ws + L.off_lists_a);
-        a.part_idx = (int32_t*)(ws + L.off_lists_a + (size_t)nq * a.nchunks * k * 4);
-        if (k <= 10) KEMR_TRY((launch_sim<10, false>(a, s)));
-        else KEMR_TRY((launch_sim<32, false>(a, s)));
-        KEMR_TRY(launch_topk_merge(a.part_scores, a.part_idx, nq, a.nchunks * k, k, top_a, (int32_t*)(top_a + (size_t)nq * k), s));
-        hipLaunchKernelGGL(simk_threshold_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, top_a, nq, k, taud, flag);
+        bool used = false;
+        KEMR_TRY(launch_gemm256u_simgmax(p.Q, nq, sample, L.m, (int)kdim, gmax, s, &used));
+        if (!used) KEMR_FAIL(KEMR_ERR_STATE, "sim_topk: the sample pass does not fit the kernel that the plan accepted");
+        hipLaunchKernelGGL(simk_threshold_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, gmax, nq, L.m / 64, k, taud, flag);
         KEMR_CHECK_LAUNCH("simk_threshold_kernel");
         KEMR_TRY(launch_gemm256u_simk(p.Q, nq, p.G, ng, (int)kdim, gallery_offset, gt_idx_dev, gt_score_dev, ahead_dev, taud, L.plan,
                                       (float*)(ws + L.off_scores), (int32_t*)(ws + L.off_base), (int32_t*)(ws + L.off_count), flag, s));
@@ -682,6 +705,25 @@ extern "C" int kemr_sim_topk(const void* q_panel_dev, int nq, const void* g_pane
     else KEMR_TRY((launch_sim<32, false>(p, s)));
     if (k == 0) return KEMR_OK;
     return launch_topk_merge(p.part_scores, p.part_idx, nq, p.nchunks * k, k, top_scores_dev, top_idx_dev, s);
+}
+
+// tools: what the candidate-list route left in a workspace after kemr_sim_topk with the same sizes (synchronises the device):
+// out[0] = overflow flag, out[1] = longest list, out[2] = list capacity, out[3] = chunks, out[4] = sampled rows,
+// out[5] = sum of the list lengths / nq (records per query, rounded down)
+extern "C" int kemr_debug_sim_lists(const void* workspace_dev, int nq, int ng, int64_t kdim, int k, int32_t* out6) {
+    if (!workspace_dev || !out6) KEMR_FAIL(KEMR_ERR_INVALID, "debug_sim_lists: null argument");
+    const SimkLayout L = simk_layout(nq, ng, kdim, k);
+    for (int i = 0; i < 6; ++i) out6[i] = 0;
+    if (!L.on) return KEMR_OK;
+    KEMR_CHECK_HIP(hipDeviceSynchronize());
+    const char* ws = (const char*)workspace_dev;
+    KEMR_CHECK_HIP(hipMemcpy(&out6[0], ws + L.off_flag, 4, hipMemcpyDeviceToHost));
+    std::vector<int32_t> counts((size_t)nq * L.plan.nchunks);
+    KEMR_CHECK_HIP(hipMemcpy(counts.data(), ws + L.off_count, counts.size() * 4, hipMemcpyDeviceToHost));
+    long long sum = 0;
+    for (int32_t c : counts) { sum += c; if (c > out6[1]) out6[1] = c; }
+    out6[2] = L.plan.cap; out6[3] = L.plan.nchunks; out6[4] = L.m; out6[5] = (int32_t)(sum / nq);
+    return KEMR_OK;
 }
 
 // tools / tests: 0 = always sim_kernel, 1 = candidate lists where they apply (default), 2 = lists AND the fallback forced to

@@ -193,6 +193,9 @@ def pair_scores(qp: Panel, gp: Panel, q_rows: torch.Tensor, g_rows: torch.Tensor
     return out
 
 
+_last_sim_ws = None
+
+
 def sim_topk(qp: Panel, gp: Panel, k: int, gallery_offset: int = 0,
              gt_idx: Optional[torch.Tensor] = None, gt_score: Optional[torch.Tensor] = None,
              ahead: Optional[torch.Tensor] = None,
@@ -212,6 +215,8 @@ def sim_topk(qp: Panel, gp: Panel, k: int, gallery_offset: int = 0,
     if ng == 0:
         return top_s.fill_(float("-inf")), top_i.fill_(-1)
     ws = torch.empty(max(int(L.kemr_sim_workspace_bytes(nq, ng, qp.kdim, k)), 256), dtype=torch.uint8, device=dev)
+    global _last_sim_ws
+    _last_sim_ws = ws           # tools/bench_sim.py reads the candidate-list statistics out of it (kemr_debug_sim_lists)
     if gt_idx is not None:
         if gt_score is None or ahead is None:
             raise RuntimeError("sim_topk: gt_idx needs gt_score and ahead")
