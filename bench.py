@@ -300,7 +300,8 @@ def main():
         # roofline of the similarity kernel at the headline size (MFMA-bound: SURVEY 8(d)); min_bytes = both panels read once +
         # the lists written
         hs = sim["q43000_bf16"]
-        result["roofline_sim"] = {"kernel": "sim_kernel + topk_merge (panel build of the queries included)", "bound": "mfma",
+        result["roofline_sim"] = {"kernel": "gemm256u_bf16_nt_kernel<SIM 3 sample pass + SIM 2 list pass> + threshold / select kernels "
+                                            "(whole kemr_sim_topk call at Q = 43000, panel build of the queries included)", "bound": "mfma",
                                   "flops": 2.0 * GALLERY * GALLERY * arch.embed_dim, "ms": hs["ms"],
                                   "achieved": hs["mfma_tflops_per_gpu"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                   "frac": hs["mfma_tflops_per_gpu"] / PEAK_BF16_TFLOPS,

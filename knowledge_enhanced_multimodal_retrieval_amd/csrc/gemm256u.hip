@@ -574,6 +574,11 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             // All of a lane's 16 candidates lie on one side of gt unless gt falls into the lane's 52-id window, so one threshold per
             // query does (sgd for "ids below gt": >= as >); the rare mixed window and a gallery's ragged last tile are recounted
             // element by element.
+            // Both halves scan in the SAME barrier interval: the leading half sits out the interval of the trailing half's last
+            // cluster, and the trailing half takes its next staging interval on its own afterwards (one extra barrier per tile
+            // for each).  Scanning one after the other -- each against one 256-cycle cluster of the other half -- left the
+            // SIMD to a single wave's dependent VALU chain at ~9 cycles per instruction (stamps, round 2); two waves interleave.
+            if (wr == 0) __builtin_amdgcn_s_barrier();
             stamp(8);
             int sl = lane;
             asm volatile("" : "+v"(sl));
@@ -593,6 +598,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
                     const int q = t_row_u + wr * 128 + mi * 16 + (sl & 15);
                     if (sl < 16 && q < p.M) p.simk_scores[(size_t)q * groups + grp] = m;
                 }
+                if (wr == 1) __builtin_amdgcn_s_barrier();
                 continue;
             }
             const int cb = p.sim_gbase + ((sim_tb + seq) << 8) + wc * 64 + (sl >> 4) * 4;       // global id of the lane's first candidate
@@ -670,6 +676,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
                     }
                 }
             }
+            if (wr == 1) __builtin_amdgcn_s_barrier();
         } else {
             // ---- epilogue (lane constants behind an opaque copy of `lane`: recomputed here, not kept across the K loop)
             int el = lane;

@@ -502,24 +502,46 @@ __global__ __launch_bounds__(256) void simk_select_kernel(const float* __restric
     for (int c0 = 0; c0 < nchunks; c0 += 64) {
         const int mine = c0 + lane < nchunks ? rec_count[(size_t)q * nchunks + c0 + lane] : 0;      // 64 list lengths at once
         const int span = min(64, nchunks - c0);
-        for (int cc = 0; cc < span; ++cc) {
-            const int cnt = __shfl(mine, cc);
-            const size_t rec0 = ((size_t)q * nchunks + c0 + cc) * cap;
-            for (int r0 = 0; r0 < cnt; r0 += 16) {                   // 16 records per step: a lane takes a quarter (4 scores) of one
-                const int rec = r0 + (lane >> 2), ni = lane & 3;
-                const bool ok = rec < cnt;
-                const float4 sc = ok ? ((const float4*)rec_scores)[(rec0 + rec) * 4 + ni] : make_float4(0.f, 0.f, 0.f, 0.f);
-                const int id0 = ok ? rec_base[rec0 + rec] + ni * 16 : 0;
-                const float v[4] = {sc.x, sc.y, sc.z, sc.w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool keep = ok && v[r] > td && id0 + r < n_end;       // id >= n_end: the gallery panel's zero pad rows
-                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
-                    const int pos = n + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                    if (keep && pos < SIMK_SELECT) { ls[w][pos] = v[r]; li[w][pos] = id0 + r; }
-                    n += __builtin_popcountll(mask);
-                }
+        // The lists are walked in units of 16 records (a lane takes a quarter -- 4 scores -- of one record); the loads of the
+        // next unit are in flight while the current one is compacted (the walk is a chain of dependent memory round trips).
+        int ucc = -1, ur0 = 0, ucnt = 0;                              // wave-uniform cursor: chunk, first record, list length
+        auto advance = [&]() {                                       // -> next unit, false when this group of lists is done
+            ur0 += 16;
+            while (ur0 >= ucnt) {
+                if (++ucc >= span) return false;
+                ucnt = __shfl(mine, ucc);
+                ur0 = 0;
             }
+            return true;
+        };
+        struct Loaded { float4 sc; int id0; bool ok; };
+        auto load = [&]() {
+            Loaded u;
+            const int rec = ur0 + (lane >> 2), ni = lane & 3;
+            const size_t rec0 = ((size_t)q * nchunks + c0 + ucc) * cap;
+            u.ok = rec < ucnt;
+            u.sc = u.ok ? ((const float4*)rec_scores)[(rec0 + rec) * 4 + ni] : make_float4(0.f, 0.f, 0.f, 0.f);
+            u.id0 = u.ok ? rec_base[rec0 + rec] + ni * 16 : 0;
+            return u;
+        };
+        bool have = advance();
+        Loaded cur{};
+        if (have) cur = load();
+        while (have) {
+            const bool more = advance();
+            Loaded nxt{};
+            if (more) nxt = load();
+            const float v[4] = {cur.sc.x, cur.sc.y, cur.sc.z, cur.sc.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool keep = cur.ok && v[r] > td && cur.id0 + r < n_end;       // id >= n_end: the gallery panel's zero pad rows
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+                const int pos = n + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                if (keep && pos < SIMK_SELECT) { ls[w][pos] = v[r]; li[w][pos] = cur.id0 + r; }
+                n += __builtin_popcountll(mask);
+            }
+            cur = nxt;
+            have = more;
         }
     }
     if (n > SIMK_SELECT) {

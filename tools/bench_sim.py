@@ -72,11 +72,14 @@ def main():
     if args.stamps:
         import ctypes as C
         import numpy as np
-        for label, k in (("rank only (SIM 1)", 0), ("lists (SIM 2)", args.k)):
+        for label, k, rank in (("rank only (SIM 1)", 0, True), ("lists + rank (SIM 2)", args.k, True), ("lists (SIM 2)", args.k, False)):
             engine.set_gemm_variant(64 << 8)
             ahead = torch.zeros(args.nq, dtype=torch.int32, device=dev)
             for _ in range(3):
-                engine.sim_topk(qp, gp, k, 0, gt, sgt, ahead)
+                if rank:
+                    engine.sim_topk(qp, gp, k, 0, gt, sgt, ahead)
+                else:
+                    engine.sim_topk(qp, gp, k, 0)
             torch.cuda.synchronize()
             buf = (C.c_uint * (1024 * 16))()
             _lib.check(_lib.lib().kemr_debug_gemm_stamps(buf, 1024 * 16), "stamps")
