@@ -126,6 +126,7 @@ struct GemmParams {
 };
 extern int g_gemm_dbg;
 extern int g_gemm_order;
+extern int g_gemm_conc;     // gemm256u: both wave halves run their epilogues in the same barrier interval
 int gemm_read_stamps(unsigned* host_out, int n_words);
 int launch_gemm256u_simgmax(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, float* out, hipStream_t stream,
                             bool* used);

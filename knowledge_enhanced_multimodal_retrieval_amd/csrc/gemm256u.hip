@@ -139,7 +139,7 @@ constexpr int GEMM256U_MAX_TILES_PER_WG = 62;         // the tile table is one l
 // ahead of the query's ground truth (reference metrics.py:13-76: Recall@K / MRR need nothing else).  One workgroup = one
 // 256-query tile x one chunk of gallery tiles (blockIdx = q_tile * nchunks + chunk); same MFMA operand roles and k order as
 // sim_kernel / pair_scores_kernel (sim.hip), so the scores are theirs bit for bit.
-template <int EPI, bool FP8, bool DBG = false, int SIM = 0>
+template <int EPI, bool FP8, bool DBG = false, int SIM = 0, bool CONC = false>
 __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmParams p) {
     constexpr int ES = FP8 ? 1 : 2;          // operand element size
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -679,13 +679,17 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             if (wr == 1) __builtin_amdgcn_s_barrier();
         } else {
             // ---- epilogue (lane constants behind an opaque copy of `lane`: recomputed here, not kept across the K loop)
+            // CONC: both halves run their epilogues in the SAME barrier interval (as the similarity scans do): the leading half
+            // sits out the interval of the trailing half's last cluster, the trailing half takes its next staging interval alone
+            // afterwards.  Each wave then has only its own 2 KiB area (single-buffered passes); two waves per SIMD interleave.
+            if (CONC && wr == 0) __builtin_amdgcn_s_barrier();
             int el = lane;
             asm volatile("" : "+v"(el));
             const int erow = el & 15, eq = el >> 4;
             const int er = el >> 3, ec = el & 7;                              // read-back: row er (+8), chunk ec
             // 16 rows x 128 B per area, chunk ^= row & 7.  Even passes use the area of wave (wid & 3), odd passes that of wave
             // (wid & 3) + 4 (8 KiB further): the wave's own and its partner's, which is idle (header)
-            const unsigned epi0 = lds_addr(smem + PEPI) + (wid & 3) * 2048;
+            const unsigned epi0 = lds_addr(smem + PEPI) + (wid & 3) * 2048 + (CONC ? wr * 8192 : 0);
             const unsigned epi_w = epi0 + erow * 128 + (((eq >> 1) ^ (erow & 7)) << 4) + (eq & 1) * 8;
             const unsigned epi_r = epi0 + er * 128 + ((ec ^ er) << 4);        // rows er and er + 8: (er + 8) & 7 == er
             const unsigned ew0 = epi_w, ew1 = epi_w ^ 32, ew2 = epi_w ^ 64, ew3 = epi_w ^ 96;      // chunk (ni*2 + (eq>>1)) ^ (erow & 7): ni flips bits 5-6
@@ -746,6 +750,19 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
                 }                                                                                                                   \
                 voff = voff8 + step8;                                                                                               \
             } while (0)
+            if constexpr (CONC) {
+                // one area: a pass's read-back must have landed before the next pass's writes (the wait of its stores covers it);
+                // the next pass's conversion (and QuickGELU) is issued in front of that wait
+                pack(acc[0]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                pack(acc[1]); KEMR_STORE_PASS(dA0, dA1, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                pack(acc[2]); KEMR_STORE_PASS(dA0, dA1, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                pack(acc[3]); KEMR_STORE_PASS(dA0, dA1, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                pack(acc[4]); KEMR_STORE_PASS(dA0, dA1, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                pack(acc[5]); KEMR_STORE_PASS(dA0, dA1, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                pack(acc[6]); KEMR_STORE_PASS(dA0, dA1, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                pack(acc[7]); KEMR_STORE_PASS(dA0, dA1, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                KEMR_STORE_PASS(dA0, dA1, 0);
+            } else {
             pack(acc[0]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
             pack(acc[1]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
             KEMR_STORE_PASS(dA0, dA1, 6); pack(acc[2]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
@@ -756,6 +773,8 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             KEMR_STORE_PASS(dB0, dB1, 6); pack(acc[7]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
             KEMR_STORE_PASS(dA0, dA1, 6);
             KEMR_STORE_PASS(dB0, dB1, 0);
+            }
+            if (CONC && wr == 1) __builtin_amdgcn_s_barrier();
     #undef KEMR_LDS_PASS
     #undef KEMR_STORE_PASS
         }
@@ -830,9 +849,9 @@ bool gemm256u_fits(const GemmParams& p, int elem_size) {
            (long)p.N * p.ldw * elem_size < (1L << 32) && rows * p.ldc * 2 < (1L << 32);
 }
 
-template <int EPI, bool FP8, bool DBG>
+template <int EPI, bool FP8, bool DBG, bool CONC>
 static int launch256u_a(const GemmParams& p, hipStream_t stream) {
-    auto kern = gemm256u_bf16_nt_kernel<EPI, FP8, DBG>;
+    auto kern = gemm256u_bf16_nt_kernel<EPI, FP8, DBG, 0, CONC>;
     static int attr_dev = -1;
     int dev = 0, num_cu = 0;
     KEMR_CHECK_HIP(hipGetDevice(&dev));
@@ -857,8 +876,12 @@ static int launch256u_a(const GemmParams& p, hipStream_t stream) {
 
 template <int EPI, bool FP8>
 static int launch256u(const GemmParams& p, hipStream_t stream) {
-    if (g_gemm_dbg && !FP8) return launch256u_a<EPI, false, true>(p, stream);
-    return launch256u_a<EPI, FP8, false>(p, stream);
+    if (g_gemm_conc) {
+        if (g_gemm_dbg && !FP8) return launch256u_a<EPI, false, true, true>(p, stream);
+        return launch256u_a<EPI, FP8, false, true>(p, stream);
+    }
+    if (g_gemm_dbg && !FP8) return launch256u_a<EPI, false, true, false>(p, stream);
+    return launch256u_a<EPI, FP8, false, false>(p, stream);
 }
 
 // tools/ only: the stamp sums of the last DBG launch with flag 64 (per workgroup: 8 K-loop intervals, K-loop tail, epilogue,

@@ -17,8 +17,8 @@ orders = [0, 3]          # 0: N fastest; 3: column groups of 4 tiles
 R1 = "v2"                 # gemm256 (variant 2, non-persistent lockstep kernel): a fixed point of comparison in the product library
 
 
-def variant(order, dbg=0):
-    return 7 | (dbg << 8) | ((order + 1) << 16)
+def variant(order, dbg=0, conc=0):
+    return 7 | (dbg << 8) | ((order + 1) << 16) | ((conc + 1) << 20)
 
 
 def ref(a, w, bias, m, epi):
@@ -61,6 +61,49 @@ for name, m, n, k, epi in shapes:
                 out.setdefault(o, []).append(e0.elapsed_time(e1) / 300 * 1e3)
         fl = 2.0 * m * n * k
         print("ab", name, {o: "%.1f us %.0f TF (%s)" % (sorted(t)[len(t) // 2], fl / sorted(t)[len(t) // 2] / 1e6, " ".join("%.0f" % x for x in t)) for o, t in out.items()}, flush=True)
+    if what in ("conc",):
+        # both halves' epilogues in the same barrier interval (conc = 1) against one after the other (0): parity, then
+        # sustained interleaved timing, then the stamp profile of the stamped instantiation
+        want = ref(a, w, bias, m, epi)
+        for cc in (0, 1):
+            engine.set_gemm_variant(variant(3, conc=cc))
+            c.zero_()
+            got = engine.op_gemm(a, w, bias, m, epi, c=c)[:m].float()
+            err = (got - want).abs().max().item()
+            assert err < 0.08 * max(1.0, want.abs().max().item() / 8), (name, cc, err)
+            if cc == 0:
+                base = got.clone()
+            else:
+                assert torch.equal(got, base), (name, "conc differs from serial epilogues")
+        out = {}
+        for rnd in range(3):
+            for cc in (0, 1):
+                engine.set_gemm_variant(variant(3, conc=cc))
+                fn = lambda: engine.op_gemm(a, w, bias, m, epi, c=c)
+                for _ in range(400):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(300):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                out.setdefault(cc, []).append(e0.elapsed_time(e1) / 300 * 1e3)
+        fl = 2.0 * m * n * k
+        print("conc", name, {o: "%.1f us %.0f TF (%s)" % (sorted(t)[1], fl / sorted(t)[1] / 1e6, " ".join("%.0f" % x for x in t)) for o, t in out.items()}, flush=True)
+        for cc in (0, 1):
+            engine.set_gemm_variant(variant(3, dbg=64, conc=cc))
+            for _ in range(200):
+                engine.op_gemm(a, w, bias, m, epi, c=c)
+            torch.cuda.synchronize()
+            buf = (C.c_uint * (256 * 16))()
+            _lib.check(_lib.lib().kemr_debug_gemm_stamps(buf, 256 * 16), "stamps")
+            st = np.frombuffer(buf, dtype=np.uint32).reshape(256, 16).astype(np.float64)
+            tiles, nt = st[:, 14], st[:, 15]
+            per_ktile = st[:, :8] / (tiles * nt)[:, None]
+            print(f"  stamps conc={cc}: " + " ".join("%.0f" % x for x in np.median(per_ktile, 0)) + f" | sum {np.median(per_ktile.sum(1)):.0f}"
+                  + f" | per tile: tail {np.median(st[:, 8] / tiles):.0f}, epilogue(H0) {np.median(st[:, 9] / tiles):.0f}", flush=True)
+        engine.set_gemm_variant(variant(3, conc=0))
     if what in ("exp",) and name.startswith("v."):
         # timing experiments of the DBG instantiation: 128 = nothing extra (calibrates the instantiation), 8 = no waits for the
         # staged pieces (garbage results), 16 = L2 prefetch PD K-tiles ahead
@@ -110,5 +153,5 @@ for name, m, n, k, epi in shapes:
                 pre = st[:, 10:14] / (tiles * nt)[:, None]
                 line += " | own work before barrier: L1 %.0f, M1 (incl. LDS wait) %.0f, M4 %.0f, M4 + piece wait %.0f" % tuple(np.median(pre, 0))
             print(line, flush=True)
-engine.set_gemm_variant(7 | (4 << 16))      # back to the default tile order (3)
+engine.set_gemm_variant(7 | (4 << 16) | (1 << 20))      # back to the default tile order (3), serial epilogues
 engine.set_gemm_variant(0)
