@@ -69,6 +69,20 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float quick_gelu(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v));
 }
+// two at a time: the scale, the + 1 and the final product as packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32, same
+// IEEE results as the scalar forms), the two transcendentals per element stay
+typedef float __attribute__((ext_vector_type(2))) f32x2_t;
+__device__ __forceinline__ f32x2_t quick_gelu2(f32x2_t v) {
+    const f32x2_t t = v * (-1.702f * 1.4426950408889634f);
+    f32x2_t e;
+    e.x = __builtin_amdgcn_exp2f(t.x);
+    e.y = __builtin_amdgcn_exp2f(t.y);
+    const f32x2_t d = e + 1.0f;
+    f32x2_t r;
+    r.x = __builtin_amdgcn_rcpf(d.x);
+    r.y = __builtin_amdgcn_rcpf(d.y);
+    return v * r;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -126,7 +140,7 @@ struct GemmParams {
 };
 extern int g_gemm_dbg;
 extern int g_gemm_order;
-extern int g_gemm_conc;     // gemm256u: both wave halves run their epilogues in the same barrier interval
+extern int g_gemm_conc;     // gemm256u: both wave halves run their epilogues in the same barrier interval (0 never, 1 always, 2 = QuickGELU epilogue only)
 int gemm_read_stamps(unsigned* host_out, int n_words);
 int launch_gemm256u_simgmax(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, float* out, hipStream_t stream,
                             bool* used);

@@ -103,7 +103,7 @@ for name, m, n, k, epi in shapes:
             per_ktile = st[:, :8] / (tiles * nt)[:, None]
             print(f"  stamps conc={cc}: " + " ".join("%.0f" % x for x in np.median(per_ktile, 0)) + f" | sum {np.median(per_ktile.sum(1)):.0f}"
                   + f" | per tile: tail {np.median(st[:, 8] / tiles):.0f}, epilogue(H0) {np.median(st[:, 9] / tiles):.0f}", flush=True)
-        engine.set_gemm_variant(variant(3, conc=0))
+        engine.set_gemm_variant(variant(3, conc=2))
     if what in ("exp",) and name.startswith("v."):
         # timing experiments of the DBG instantiation: 128 = nothing extra (calibrates the instantiation), 8 = no waits for the
         # staged pieces (garbage results), 16 = L2 prefetch PD K-tiles ahead
@@ -153,5 +153,5 @@ for name, m, n, k, epi in shapes:
                 pre = st[:, 10:14] / (tiles * nt)[:, None]
                 line += " | own work before barrier: L1 %.0f, M1 (incl. LDS wait) %.0f, M4 %.0f, M4 + piece wait %.0f" % tuple(np.median(pre, 0))
             print(line, flush=True)
-engine.set_gemm_variant(7 | (4 << 16) | (1 << 20))      # back to the default tile order (3), serial epilogues
+engine.set_gemm_variant(7 | (4 << 16) | (3 << 20))      # back to the default tile order (3) and epilogue choice (2)
 engine.set_gemm_variant(0)
