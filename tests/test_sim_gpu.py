@@ -305,6 +305,18 @@ def test_topk_by_candidate_lists_is_the_kernel_path_bit_for_bit(device, nq, ng, 
     for mode in (1, 2):
         for a, b in zip(out[0], out[mode]):
             assert torch.equal(a, b), mode
+    if ng >= 2 * 8192 + 100:
+        # two shards, both on the list route, ground truths mostly in the OTHER shard: merged lists and summed counts
+        cut = (ng // 2) // 7 * 7 + 3
+        ahead2 = torch.zeros(nq, dtype=torch.int32, device=device)
+        ps, pi = [], []
+        for lo, hi in ((0, cut), (cut, ng)):
+            gps = engine.build_panel([gal[lo:hi]], _lib.SIDE_GALLERY, terms)
+            s_, i_ = engine.sim_topk(qp, gps, k, off + lo, gtg, sgt, ahead2)
+            ps.append(s_)
+            pi.append(i_)
+        ms, mi = engine.topk_merge(torch.stack(ps, 1), torch.stack(pi, 1), k)
+        assert torch.equal(ms, out[1][0]) and torch.equal(mi, out[1][1]) and torch.equal(ahead2, out[1][2])
     if nq * ng <= 2e7:
         S = engine.scores_dense(qp, gp)
         order = torch.sort(S, dim=1, descending=True, stable=True)
