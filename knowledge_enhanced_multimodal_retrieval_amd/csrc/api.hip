@@ -434,6 +434,7 @@ extern "C" int kemr_encode_text(kemr_model* m, const int32_t* ids_dev, int batch
 extern "C" int kemr_set_gemm_variant(int variant) {
     g_gemm_dbg = (variant >> 8) & 0xff;   // bits 8..15: timing-experiment flags (tools/ only)
     if ((variant >> 16) & 0xf) g_gemm_order = ((variant >> 16) & 0xf) - 1;
+    if ((variant >> 24) & 0xf) g_attn_waves = ((variant >> 24) & 0xf) - 1;   // bits 24..27: attention waves per workgroup for T = 257 (+ 1; 0 / 4 default, 6) (tools/ only)
     if ((variant >> 20) & 0x3) g_gemm_conc = ((variant >> 20) & 0x3) - 1;     // bits 20..21: gemm256u concurrent epilogues (0 never / 1 always / 2 QuickGELU only) + 1 (tools/ only; 0 keeps the current setting)   // bits 16..19: gemm256u tile order + 1 (tools/ only; 0 keeps the current one)
     variant &= 0xff;
     if (variant < 0 || variant > 9) KEMR_FAIL(KEMR_ERR_INVALID, "set_gemm_variant: 0 auto, 1 = 128x128, 2 = 256x256 lockstep, 3 = 256x256 staggered, 4 / 5 = persistent 8-wave (4 / 2 phases per K-tile), 6 = persistent 4-wave, 7 = persistent 8-wave with one K-tile pipeline across tiles, 8 = skinny-M split-K, 9 = persistent 4-wave with register-staged operands");

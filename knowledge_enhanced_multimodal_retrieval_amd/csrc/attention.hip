@@ -1,6 +1,11 @@
 // Multi-head self-attention for the CLIP towers (head dim 64; T = 257 / 197 / 50 non-causal, T = 77 causal).
 //
-// One 256-thread workgroup per (image or text, head).  The whole K and V of that head (T <= 288 keys,
+// One workgroup of NW waves per (image or text, head): NW = 4, or 5 for the 77-token text tower (5 query tiles: one per wave
+// instead of 2 / 1 / 1 / 1; with the key tiles behind the causal diagonal skipped: 27.7 -> 22.7 us per launch at B = 255).
+// Tried and dropped for T = 257 (17 query tiles = 5 / 4 / 4 / 4 per wave; round 2, same device): 6 waves per workgroup
+// (3 / 3 / 3 / 3 / 3 / 2) 157 -> 173 us (still there as NW = 6 for tools); the single-query 17th tile split over the keys
+// of three waves with an LDS merge 157 -> 161 us.  Two workgroups share a CU and interleave; the fifth tile of wave 0 is not
+// what the launch waits for.  The whole K and V of that head (T <= 288 keys,
 // 2 x 36 KB) sit in LDS; every wave owns 16-query tiles and, because T is short, keeps the full score
 // row in registers -- plain softmax, no online rescaling.  MFMA v_mfma_f32_16x16x32_bf16 throughout:
 //   S^T tile = K_tile . Q^T      (A = K rows from LDS, B = Q rows straight from HBM)  -> a lane holds
@@ -24,13 +29,14 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
 // TC > 0: the sequence length is a compile-time constant (257 / 77: the shapes that matter), so every pad-key mask and
 // tile-skip test folds away; TC == 0 keeps T a run-time value (other models, tests).  With a run-time T the uniform
 // conditions of the 18 unrolled tiles overflowed the SGPR file (150+ v_readlane/v_writelane spills per query tile).
-template <int NT32, bool CAUSAL, int TC>   // keys padded to NT32 * 32
-__global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+template <int NT32, bool CAUSAL, int TC, int NW = 4>   // keys padded to NT32 * 32; NW waves per workgroup
+__global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            int T_rt, int width) {
     const int T = TC > 0 ? TC : T_rt;
     constexpr int TP = NT32 * 32;
     constexpr int NT16 = NT32 * 2;
-    constexpr int NCH = (TP * 8 + 255) / 256;          // 16-byte chunks of K (and of V) per thread
+    constexpr int NTH = NW * 64;
+    constexpr int NCH = (TP * 8 + NTH - 1) / NTH;      // 16-byte chunks of K (and of V) per thread
     constexpr float LOG2E = 1.4426950408889634f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
         uint4 kv[NCH], vv[NCH];
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NTH;
             const int row = idx >> 3, c = idx & 7;
             // branch-free: pad rows load the last valid row and are zeroed by a select at the LDS write (a conditional
             // load, or a select right here, makes hipcc wait for the loads in the middle of the batch)
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
         }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NTH;
             const int row = idx >> 3, c = idx & 7;
             if (idx < TP * 8) {
                 const unsigned keep = row < T ? 0xffffffffu : 0u;       // component-wise: a struct select went to scratch
@@ -83,11 +89,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     }
     __syncthreads();
 
-    for (int qt = wid; qt < nqt; qt += 4) {            // wave-uniform trip count: EXEC stays full for the tr reads
+    for (int qt = wid; qt < nqt; qt += NW) {           // wave-uniform trip count: EXEC stays full for the tr reads
         const int q = qt * 16 + lrow;
         bf16x8 qf[2] = {qn[0], qn[1]};
-        if (qt + 4 < nqt) {                            // prefetch the next query tile of this wave
-            const int q2 = q + 64;
+        if (qt + NW < nqt) {                           // prefetch the next query tile of this wave
+            const int q2 = q + NW * 16;
             const int qc = q2 < T ? q2 : T - 1;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) qn[kk] = *(const bf16x8*)(base + (size_t)qc * ld + kk * 32 + lq * 8);
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
             for (int j = 0; j < G; ++j) {
                 const int t = g * G + j;
                 s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (t * 16 < T) {                      // tiles made only of pad keys are skipped (uniform)
+                if (t * 16 < T && (!CAUSAL || t <= qt)) {      // tiles made only of pad keys -- or, causal, of keys behind the query tile -- are skipped (uniform); the mask below covers them
                     s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[g & 1][j][0], qf[0], s[t], 0, 0, 0);
                     s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[g & 1][j][1], qf[1], s[t], 0, 0, 0);
                 }
@@ -141,14 +147,20 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float mxl = mx * LOG2E;
-        float sum = 0.f;
+        // exp(s - max) = exp2(s * log2e - max * log2e); masked keys -> 0.  The multiply-add and the row sum run two elements per
+        // instruction (v_pk_fma_f32 / v_pk_add_f32): the softmax is issue-bound, the MFMAs hide behind it
+        f32x2_t sum2 = {0.f, 0.f};
+        const f32x2_t l2 = {LOG2E, LOG2E}, nm = {-mxl, -mxl};
 #pragma unroll
-        for (int t = 0; t < NT16; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[t][r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], LOG2E, -mxl));   // exp(s - max); masked keys -> 0
-                sum += s[t][r];
-            }
+        for (int t = 0; t < NT16; ++t) {
+            f32x2_t a = f32x2_t{s[t][0], s[t][1]} * l2 + nm, c = f32x2_t{s[t][2], s[t][3]} * l2 + nm;
+            a.x = __builtin_amdgcn_exp2f(a.x); a.y = __builtin_amdgcn_exp2f(a.y);
+            c.x = __builtin_amdgcn_exp2f(c.x); c.y = __builtin_amdgcn_exp2f(c.y);
+            s[t][0] = a.x; s[t][1] = a.y; s[t][2] = c.x; s[t][3] = c.y;
+            sum2 += a;
+            sum2 += c;
+        }
+        float sum = sum2.x + sum2.y;
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
 
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
         load_v(0, vfr[0]);
 #pragma unroll
         for (int u = 0; u < NT32; ++u) {
-            if (u * 32 >= T) continue;                 // all-pad key block (uniform)
+            if (u * 32 >= T || (CAUSAL && u * 32 > qt * 16 + 15)) continue;      // all-pad key block, or all behind the diagonal: P = 0 (uniform)
             if (u + 1 < NT32 && (u + 1) * 32 < T) load_v(u + 1, vfr[(u + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
             union { bf16x8 v; uint32_t w[4]; } pf;
@@ -200,16 +212,26 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     }
 }
 
+int g_attn_waves = 0;      // tools: 0 = the default choice below, else waves per workgroup for the 257-token shape (4 or 6)
+
 template <int NT32>
 static int launch_nt(const bf16_t* qkv, bf16_t* out, int batch, int t, int width, int causal, hipStream_t stream) {
     constexpr int smem = NT32 * 32 * 128 * 2;
     const dim3 grid(width / 64, batch);
     ProfScope prof(PROF_ATTENTION, stream);
     void (*kern)(const bf16_t*, bf16_t*, int, int);
-    if (causal) kern = (NT32 == 3 && t == 77) ? attention_kernel<NT32, true, NT32 == 3 ? 77 : 0> : attention_kernel<NT32, true, 0>;
-    else kern = (NT32 == 9 && t == 257) ? attention_kernel<NT32, false, NT32 == 9 ? 257 : 0> : attention_kernel<NT32, false, 0>;
+    int threads = 256;
+    if (causal) {
+        if (NT32 == 3 && t == 77) { kern = attention_kernel<NT32, true, NT32 == 3 ? 77 : 0, NT32 == 3 ? 5 : 4>; threads = 320; }
+        else kern = attention_kernel<NT32, true, 0>;
+    } else if (NT32 == 9 && t == 257) {
+        if (g_attn_waves == 6) { kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, NT32 == 9 ? 6 : 4>; threads = 384; }
+        else kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0>;
+    } else {
+        kern = attention_kernel<NT32, false, 0>;
+    }
     KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, qkv, out, t, width);
+    hipLaunchKernelGGL(kern, grid, dim3(threads), smem, stream, qkv, out, t, width);
     KEMR_CHECK_LAUNCH("attention_kernel");
     return KEMR_OK;
 }
