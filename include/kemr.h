@@ -152,7 +152,7 @@ int kemr_panel_build(const float* const* parts_dev, const float* part_scale, con
  *            queries: bonus_rowptr int32 [nq+1], bonus_col int32 (GLOBAL ids, ascending within a row),
  *            bonus_val fp32.  Weighted fusion's alpha is folded into the query panel (part_scale).
  *   Galleries of >= 8192 rows with >= 256 queries and no bonus list take their scores from the encoder GEMM's main loop as
- *   well: thresholds from the exact top-k against a 1/12 sample of the gallery, one 256 x 256-tile pass that appends the
+ *   well: thresholds from the block maxima of a strided sample of the gallery (about a tenth of the rows at k = 10), one 256 x 256-tile pass that appends the
  *   candidates above a query's threshold to its lists (the rank count rides along), one selection pass.  Same scores, same
  *   order rule, same outputs bit for bit; lists that overflow re-run the slower kernel on the device (no host round trip).
  *   workspace >= kemr_sim_workspace_bytes(nq, ng, kdim, k), 256-byte aligned */

@@ -146,7 +146,7 @@ int gemm_read_stamps(unsigned* host_out, int n_words);
 int launch_gemm256u_simgmax(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, float* out, hipStream_t stream,
                             bool* used);
 struct SimkPlan { int nchunks, tpc, cap; size_t scores_bytes, base_bytes, count_bytes; };
-int gemm256u_simk_plan(int nq, int ng, int kdim, double hits_per_query, SimkPlan* plan, bool* ok);
+int gemm256u_simk_plan(int nq, int ng, int kdim, double hits_per_query, double spread, SimkPlan* plan, bool* ok);
 int launch_gemm256u_simk(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, long long gallery_offset,
                          const int32_t* gt_idx, const float* gt_score, int32_t* ahead, const float* taud, const SimkPlan& plan,
                          float* rec_scores, int32_t* rec_base, int32_t* rec_count, int32_t* flag, hipStream_t stream);

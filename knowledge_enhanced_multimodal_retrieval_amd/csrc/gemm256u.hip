@@ -964,18 +964,17 @@ int launch_gemm256u_simrank(const bf16_t* q_panel, int nq, const bf16_t* g_panel
 }
 
 // Top-k candidate pass (SIM == 2).  hits_per_query: the expected number of (lane, query) records per query over the whole
-// gallery (the caller derives it from how its thresholds were chosen); a list holds 3x the mean per chunk + 8, rounded up
-// to a power of two.  *ok = false: the shape is outside the kernel.
-int gemm256u_simk_plan(int nq, int ng, int kdim, double hits_per_query, SimkPlan* plan, bool* ok) {
+// gallery, spread: how far above its mean a list may run (the caller derives both from how its thresholds were chosen: the
+// count is Poisson around a Gamma(k)-distributed mean, whose upper tail is long -- over 10^5 lists a capacity of 3x the mean
+// overflowed in every second call at k = 10, round 2).  A list holds spread x the mean per chunk + 16, rounded up to a power
+// of two.  *ok = false: the shape is outside the kernel.
+int gemm256u_simk_plan(int nq, int ng, int kdim, double hits_per_query, double spread, SimkPlan* plan, bool* ok) {
     *ok = false;
     int tpc = 0;
     const int nch = sim_chunking(nq, ng, kdim, 0, &tpc);
     if (nch <= 0) return KEMR_OK;
-    // Records per (query, chunk) list: Poisson around a Gamma(k)-distributed mean (the threshold is an order statistic of a
-    // sample), whose upper tail is long: over 10^5 lists a capacity of 3x the mean overflowed in every second call (measured,
-    // round 2), 5x + 16 is beyond 10^-10 per list
     int cap = 16;
-    const double want = 5.0 * hits_per_query / nch + 16.0;
+    const double want = (spread < 3.0 ? 3.0 : spread) * hits_per_query / nch + 16.0;
     while (cap < want && cap < 4096) cap *= 2;
     plan->nchunks = nch; plan->tpc = tpc; plan->cap = cap;
     const size_t lists = (size_t)nq * nch;

@@ -14,6 +14,7 @@
 // Per (query, gallery chunk) partial lists go to the workspace and are merged by topk_merge_kernel, the same
 // kernel that merges per-GPU shards.  Order rule everywhere: higher score first, then lower candidate id.
 #include "common.h"
+#include <cmath>
 #include <vector>
 
 namespace kemr {
@@ -440,7 +441,7 @@ extern "C" int kemr_panel_build(const float* const* parts_dev, const float* part
 
 // ------------------------------------------------------------------------------------------------ top-k by candidate lists
 // Large galleries: the scores come out of the persistent GEMM's K loop (gemm256u.hip, SIM == 2) instead of sim_kernel.
-//   1. thresholds: a strided SAMPLE of the gallery (1/12 of the rows) goes through the same K loop, which keeps the best
+//   1. thresholds: a strided SAMPLE of the gallery (m rows, from k: simk_layout) goes through the same K loop, which keeps the best
 //      score of every query within each block of 64 sampled rows (SIM == 3); the k-th largest of these block maxima is the
 //      score of k distinct gallery items, hence a lower bound of the k-th score of the gallery: every member of the true
 //      top-k scores >= it -- whatever the data, the lists below contain the answer.
@@ -607,13 +608,21 @@ static SimkLayout simk_layout(int nq, int ng, int64_t kdim, int k) {
     SimkLayout L;
     L.bytes = sim_lists_bytes(nq, ng, k);
     if (k < 1 || nq < 256 || ng < 8192 || kdim % 64 != 0 || kdim < 128 || kdim > 65536) return L;
-    int m = (int)round_up((int64_t)ng / 12, 256);
+    // Sampled rows m: the entries >= threshold a query brings to the selection number about 1.15 k ng / m (the k-th block
+    // maximum sits a little below the k-th item of the sample; measured 1.1x), Gamma(k)-distributed around that mean: the
+    // smaller k, the longer the tail (k = 1: exponential).  spread(k) ~ the 1 - 1e-8 quantile over the mean (20.5 / 6.3 / 4.1 /
+    // 2.4 for k = 1 / 5 / 10 / 32).  m is chosen so that mean x spread fits the selection's SIMK_SELECT entries (k = 10 at
+    // ng = 43 000: 4 096 rows, 121 entries; k = 32: 7 680 rows; k = 1: 2 048 rows); where the largest sample cannot do that the
+    // route is off.  The per-(query, chunk) lists are sized with the same spread.
+    const double spread = 1.0 + 5.5 / sqrt((double)k) + 14.0 / k;
+    const double mean_max = SIMK_SELECT / spread;
+    int m = (int)round_up((int64_t)ceil(1.15 * k * (double)ng / mean_max), 256);
     const int m_min = (int)round_up(64 * (int64_t)k, 256);                     // k block maxima need k blocks of 64 rows
-    m = m < 1024 ? 1024 : (m > 8192 ? 8192 : m);
+    m = m < 1024 ? 1024 : m;
     m = m < m_min ? m_min : m;
+    if (m > 8192) return L;
     bool ok = false;
-    // expected records per query: the k-th block maximum sits a little below the k-th item of the sample (measured: 1.1x)
-    if (gemm256u_simk_plan(nq, ng, (int)kdim, 1.15 * k * ng / m, &L.plan, &ok) != KEMR_OK || !ok) return L;
+    if (gemm256u_simk_plan(nq, ng, (int)kdim, 1.15 * k * ng / m, spread, &L.plan, &ok) != KEMR_OK || !ok) return L;
     size_t at = L.bytes;
     auto take = [&](size_t b) { const size_t o = at; at += (size_t)round_up((int64_t)b, 256); return o; };
     L.off_sample = take((size_t)m * kdim * 2);

@@ -26,17 +26,18 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--routes", default="0,1")
+    ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--stamps", action="store_true", help="in-kernel cycle split of the list pass (stamped instantiation)")
     ap.add_argument("--device-rng", action="store_true", help="the data bench.py uses (device generator, seed 7)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     src = torch.arange(args.nq) % args.ng
     if args.device_rng:
-        gg = torch.Generator(device=dev).manual_seed(7)
+        gg = torch.Generator(device=dev).manual_seed(7 + args.seed)
         gal = torch.nn.functional.normalize(torch.randn(args.ng, args.d, generator=gg, device=dev), dim=-1)
         qry = torch.nn.functional.normalize(gal[src.to(dev)] + 0.04 * torch.randn(args.nq, args.d, generator=gg, device=dev), dim=-1)
     else:
-        g = torch.Generator().manual_seed(0)
+        g = torch.Generator().manual_seed(args.seed)
         gal = torch.nn.functional.normalize(torch.randn(args.ng, args.d, generator=g), dim=-1).to(dev)
         qry = torch.nn.functional.normalize(gal[src.to(dev)] + 0.04 * torch.randn(args.nq, args.d, generator=g).to(dev), dim=-1)
     qp = engine.build_panel([qry], _lib.SIDE_QUERY, args.terms)
