@@ -38,6 +38,14 @@
 // partner's (wid ^ 4) and the LDS round trip of pass mi + 1 hides behind the stores of pass mi.  (Stamps: 3 300 cycles per
 // wave half and tile for the single-buffered form, 4 400 for a register-only form with v_permlane16_swap and 64-byte row
 // segments per store instruction - the full-line form is the one to keep.)
+// CONC (the default for the QuickGELU epilogue only): both halves in the SAME barrier interval, each wave on its own area
+// single-buffered; the next pass's QuickGELU arithmetic covers the LDS round trip (fc1: 11.1 k -> 9.2 k cycles per tile for
+// both halves; +-0 on the plain epilogue).
+//
+// SIM = 1 / 2 / 3 (launch_gemm256u_simrank / _simk / _simgmax, called from sim.hip): the same K loop as the scoring half of the
+// retrieval path -- A = query panel, W = gallery panel, C never written; the epilogue is a register scan of the accumulators
+// (rank count / rank count + candidate lists / block maxima of a gallery sample); see the comments at the template and at
+// the scan.  One workgroup = one 256-query tile x one chunk of gallery tiles; both halves scan in the same barrier interval.
 #include "common.h"
 #include <type_traits>
 // (hipcc misses odr-uses inside asm operands of generic lambdas: the hooks below name their captures, which it then calls unused)
