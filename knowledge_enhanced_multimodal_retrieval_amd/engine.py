@@ -19,6 +19,25 @@ MAX_IMAGE_BATCH = 255
 MAX_TEXT_BATCH = 851
 
 
+def tile_friendly_batch(tokens: int, width: int, lo: int, hi: int, num_cu: int = 256) -> int:
+    """Items per encoder call, in [lo, hi], that fill the persistent GEMM's rounds best: the towers' four GEMMs have
+    ceil(items * tokens / 256) x (3W | W | 4W | W) / 256 output tiles each and run ceil(tiles / CUs) rounds over the CUs, so a
+    call is as fast as its emptiest round allows (255 texts of ViT-L/14: 231 out-proj tiles on 256 CUs, 90 %; 564 texts: 510
+    tiles in two rounds, 99.6 %).  Weighted by the GEMMs' FLOPs; among near-equal sizes the largest (fewer launches per item:
+    measured 64.6 k texts/s at 255, 66.6 k at 282, 71.4 k at 564)."""
+    effs = {}
+    for items in range(lo, hi + 1):
+        row_tiles = -(-items * tokens // 256)
+        num = den = 0.0
+        for n_mult, weight in ((3, 3.0), (1, 1.0), (4, 4.0), (1, 4.0)):      # QKV, out-proj, fc1, fc2 (K = 4W)
+            tiles = row_tiles * (n_mult * width // 256)
+            num += weight * (items * tokens / 256.0) * (n_mult * width / 256.0)      # useful tile-equivalents
+            den += weight * -(-tiles // num_cu) * num_cu                             # tile slots of the rounds it takes
+        effs[items] = num / den
+    top = max(effs.values())
+    return max(i for i, e in effs.items() if e >= top - 2e-3)
+
+
 def _stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 

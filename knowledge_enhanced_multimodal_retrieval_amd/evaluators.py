@@ -23,6 +23,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from . import _lib
+from . import engine
 from . import metrics as M
 from . import sparql_fusion as SF
 from .datasets import CLIPEvalDatasetHF, CollateAndTokenize, SyntheticRawImageDataset, SyntheticRetrievalDataset, collate_fn_eval
@@ -81,23 +82,39 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
     loader = eval_loader(dataset, batch_size, seed, num_workers, tokenize_fn, pin=device.type == "cuda")
     img, qry, tgt, uuids = [], [], [], []
     logger.info(f"Computing embeddings for {len(dataset)} samples...")
-    # The loader's batch size is the host pipeline's business (the reference scripts pass 64); the encoders are fed
-    # ENCODE_ITEMS items at a time whatever it is: 255 images are 65 535 token rows = 256 row tiles of the persistent GEMM,
-    # while e.g. 64 images are 65 row tiles -> 260 tiles on 256 CUs, a second round for 4 tiles.  Rows are independent,
-    # so the embeddings do not depend on the grouping.
-    pend_i, pend_q, pend_t, pending = [], [], [], 0
+    # The loader's batch size is the host pipeline's business (the reference scripts pass 64); the encoders are fed the number
+    # of items per call that fills the persistent GEMM's rounds (engine.tile_friendly_batch), whatever it is: 255 images of
+    # ViT-L/14 are 65 535 token rows = 256 row tiles, while e.g. 64 images are 65 row tiles -> 260 tiles on 256 CUs, a second
+    # round for 4 tiles; texts go 565 to a call (queries and targets of 282 items together: 170 row tiles, every GEMM within
+    # 0.4 % of whole rounds; 255 texts leave 10 % of the out-proj round empty).  Rows are independent, so the embeddings do
+    # not depend on the grouping.
+    arch = getattr(model, "arch", None)
+    n_img = ENCODE_ITEMS if arch is None else engine.tile_friendly_batch(arch.v_tokens, arch.v_width, ENCODE_ITEMS // 2, ENCODE_ITEMS)
+    n_txt = ENCODE_ITEMS if arch is None else max(1, engine.tile_friendly_batch(arch.ctx, arch.t_width, ENCODE_ITEMS, 600) // 2)
+    pend_i, pend_q, pend_t = [], [], []
+    count = {"i": 0, "t": 0}
 
-    def flush(final: bool):
-        nonlocal pending
-        take = pending if final else (pending // ENCODE_ITEMS) * ENCODE_ITEMS      # whole encoder calls; the rest waits
+    def flush_images(final: bool):
+        take = count["i"] if final else (count["i"] // n_img) * n_img              # whole encoder calls; the rest waits
         if take <= 0:
             return
-        ci, cq, ct = torch.cat(pend_i), torch.cat(pend_q), torch.cat(pend_t)
+        ci = torch.cat(pend_i)
         img.append(model.encode_image(ci[:take], normalize=True))
-        qry.append(model.encode_text(cq[:take], normalize=True))
-        tgt.append(model.encode_text(ct[:take], normalize=True))
-        pend_i[:], pend_q[:], pend_t[:] = [ci[take:]], [cq[take:]], [ct[take:]]
-        pending -= take
+        pend_i[:] = [ci[take:]]
+        count["i"] -= take
+
+    def flush_texts(final: bool):
+        take = count["t"] if final else (count["t"] // n_txt) * n_txt
+        if take <= 0:
+            return
+        cq, ct = torch.cat(pend_q), torch.cat(pend_t)
+        for s0 in range(0, take, n_txt):                                           # queries and targets of n_txt items in ONE call
+            s1 = min(take, s0 + n_txt)
+            both = model.encode_text(torch.cat([cq[s0:s1], ct[s0:s1]]), normalize=True)
+            qry.append(both[: s1 - s0])
+            tgt.append(both[s1 - s0:])
+        pend_q[:], pend_t[:] = [cq[take:]], [ct[take:]]
+        count["t"] -= take
 
     gpu_pre = None
     for images, q_ids, t_ids, ids in loader:
@@ -108,11 +125,15 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
         pend_i.append(images.to(device, non_blocking=True))
         pend_q.append(q_ids.to(device, non_blocking=True))
         pend_t.append(t_ids.to(device, non_blocking=True))
-        pending += int(images.shape[0])
+        count["i"] += int(images.shape[0])
+        count["t"] += int(images.shape[0])
         uuids.extend(ids)
-        if pending >= ENCODE_ITEMS:
-            flush(False)
-    flush(True)
+        if count["i"] >= n_img:
+            flush_images(False)
+        if count["t"] >= n_txt:
+            flush_texts(False)
+    flush_images(True)
+    flush_texts(True)
     return torch.cat(img), torch.cat(qry), torch.cat(tgt), uuids
 
 

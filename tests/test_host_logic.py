@@ -290,3 +290,13 @@ def test_bonus_of_pairs_vectorised_matches_loop():
             if col[j] == gt[i]:
                 want[i] += val[j]
     np.testing.assert_allclose(got, want, rtol=1e-6)
+
+
+def test_tile_friendly_batch_sizes():
+    """Items per encoder call that fill the persistent GEMM's rounds on 256 CUs: 255 images (256 row tiles) and 565 texts (170 row
+    tiles: 510 / 1530 / 2040 tiles = 1.99 / 5.98 / 7.97 rounds) for ViT-L/14; never outside the asked range."""
+    from knowledge_enhanced_multimodal_retrieval_amd import engine
+    assert engine.tile_friendly_batch(257, 1024, 128, 255) == 255
+    assert engine.tile_friendly_batch(77, 768, 255, 600) == 565
+    assert engine.tile_friendly_batch(77, 768, 255, 300) in range(255, 301)
+    assert engine.tile_friendly_batch(77, 512, 100, 100) == 100
