@@ -118,6 +118,7 @@ def main():
                     help="bf16 operands with a bf16 (default, the product's default) or fp32 residual stream; fp8 variants")
     ap.add_argument("--image-slice", type=int, default=0, help="experiment: images per encoder launch (default: the engine's 255)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="A/B only: force a GEMM tile variant (0 = the library's choice)")
+    ap.add_argument("--text-group", type=int, default=0, help="texts per encoder call (0 = engine.tile_friendly_batch: 565 for ViT-L/14; 255 = one call per text column and step, round 1 / early round 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sim", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp8 / bf16-res16 sub-results (two more engines, ~20 steps each)")
@@ -162,7 +163,7 @@ def main():
     # texts a step brings are pooled and go text_group = 565 to a call (170 row tiles: every text GEMM within 0.4 % of whole
     # rounds; 255 leave 10 % of the out-proj round empty), the pool's rest is encoded when the timed region ends.  Every step
     # still encodes exactly B images + 2 B texts on average, and the region as a whole exactly steps x (B + 2 B) items.
-    text_group = engine.tile_friendly_batch(arch.ctx, arch.t_width, B, 600) if B == 255 else 2 * B
+    text_group = args.text_group or (engine.tile_friendly_batch(arch.ctx, arch.t_width, B, 600) if B == 255 else 2 * B)
     text_pool = torch.cat([q_ids, t_ids] * (-(-text_group // (2 * B))))[:text_group].contiguous()
 
     class Stepper:
