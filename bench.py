@@ -118,7 +118,7 @@ def main():
                     help="bf16 operands with a bf16 (default, the product's default) or fp32 residual stream; fp8 variants")
     ap.add_argument("--image-slice", type=int, default=0, help="experiment: images per encoder launch (default: the engine's 255)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="A/B only: force a GEMM tile variant (0 = the library's choice)")
-    ap.add_argument("--text-group", type=int, default=0, help="texts per encoder call (0 = engine.tile_friendly_batch: 565 for ViT-L/14; 255 = one call per text column and step, round 1 / early round 2)")
+    ap.add_argument("--text-group", type=int, default=0, help="texts per encoder call (0 = engine.tile_friendly_batch: 851 for ViT-L/14; 255 = one call per text column and step, round 1 / early round 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sim", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp8 / bf16-res16 sub-results (two more engines, ~20 steps each)")
@@ -160,10 +160,10 @@ def main():
     t_ids = synthetic_ids(arch, B, 4321 + rank).to(dev)
 
     # Encoder calls sized for the persistent GEMM's rounds (engine.tile_friendly_batch): B = 255 images are 256 row tiles; the 2 B
-    # texts a step brings are pooled and go text_group = 565 to a call (170 row tiles: every text GEMM within 0.4 % of whole
-    # rounds; 255 leave 10 % of the out-proj round empty), the pool's rest is encoded when the timed region ends.  Every step
+    # texts a step brings are pooled and go text_group = 851 to a call (256 row tiles: whole rounds in every text GEMM; 255 texts
+    # leave 10 % of the out-proj round empty; same box: 16 340 items/s at 255, 16 590 at 565, 16 710 at 848), the pool's rest is encoded when the timed region ends.  Every step
     # still encodes exactly B images + 2 B texts on average, and the region as a whole exactly steps x (B + 2 B) items.
-    text_group = args.text_group or (engine.tile_friendly_batch(arch.ctx, arch.t_width, B, 600) if B == 255 else 2 * B)
+    text_group = args.text_group or (engine.tile_friendly_batch(arch.ctx, arch.t_width, B, engine.MAX_TEXT_BATCH) if B == 255 else 2 * B)
     text_pool = torch.cat([q_ids, t_ids] * (-(-text_group // (2 * B))))[:text_group].contiguous()
 
     class Stepper:
@@ -267,7 +267,7 @@ def main():
             tj = json.load(f)
         traffic, traffic_source = tj.get("bytes_per_launch"), {k: tj.get(k) for k in ("profile", "round", "commit", "algorithmic_bytes_per_launch")}
     result["roofline"] = {
-        "kernel": "gemm256u_bf16_nt_kernel (all launches of the GEMM class timed by hipEvents on the launch stream over 10 steps: the persistent GEMMs of the image calls and of the 565-text calls + the patch-embedding GEMM)",
+        "kernel": "gemm256u_bf16_nt_kernel (all launches of the GEMM class timed by hipEvents on the launch stream over 10 steps: the persistent GEMMs of the image calls and of the pooled text calls + the patch-embedding GEMM)",
         "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
         "launches_per_step": round(gemm_n, 1), "avg_launch_us": 1e3 * gemm_ms / max(gemm_n, 1),

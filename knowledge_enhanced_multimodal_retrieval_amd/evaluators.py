@@ -85,12 +85,12 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
     # The loader's batch size is the host pipeline's business (the reference scripts pass 64); the encoders are fed the number
     # of items per call that fills the persistent GEMM's rounds (engine.tile_friendly_batch), whatever it is: 255 images of
     # ViT-L/14 are 65 535 token rows = 256 row tiles, while e.g. 64 images are 65 row tiles -> 260 tiles on 256 CUs, a second
-    # round for 4 tiles; texts go 565 to a call (queries and targets of 282 items together: 170 row tiles, every GEMM within
-    # 0.4 % of whole rounds; 255 texts leave 10 % of the out-proj round empty).  Rows are independent, so the embeddings do
+    # round for 4 tiles; texts go 850 to a call (queries and targets of 425 items together: 256 row tiles, whole rounds in every
+    # GEMM; 255 texts leave 10 % of the out-proj round empty).  Rows are independent, so the embeddings do
     # not depend on the grouping.
     arch = getattr(model, "arch", None)
     n_img = ENCODE_ITEMS if arch is None else engine.tile_friendly_batch(arch.v_tokens, arch.v_width, ENCODE_ITEMS // 2, ENCODE_ITEMS)
-    n_txt = ENCODE_ITEMS if arch is None else max(1, engine.tile_friendly_batch(arch.ctx, arch.t_width, ENCODE_ITEMS, 600) // 2)
+    n_txt = ENCODE_ITEMS if arch is None else max(1, engine.tile_friendly_batch(arch.ctx, arch.t_width, ENCODE_ITEMS, engine.MAX_TEXT_BATCH) // 2)
     pend_i, pend_q, pend_t = [], [], []
     count = {"i": 0, "t": 0}
 

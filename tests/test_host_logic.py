@@ -298,5 +298,6 @@ def test_tile_friendly_batch_sizes():
     from knowledge_enhanced_multimodal_retrieval_amd import engine
     assert engine.tile_friendly_batch(257, 1024, 128, 255) == 255
     assert engine.tile_friendly_batch(77, 768, 255, 600) == 565
+    assert engine.tile_friendly_batch(77, 768, 255, 851) == 851
     assert engine.tile_friendly_batch(77, 768, 255, 300) in range(255, 301)
     assert engine.tile_friendly_batch(77, 512, 100, 100) == 100
