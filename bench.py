@@ -102,6 +102,22 @@ def gemm_flops_per_step(arch, batch):
     return fi + patch + ft, li + 1 + 2 * lt      # two encode_text calls (query, target) per step
 
 
+def gemm256u_census(arch, calls):
+    """(launches, algorithmic bytes) of the persistent-GEMM launches behind a list of encoder calls [(kind, items)]: per layer
+    QKV, out-proj, fc1, fc2 with A + W read once and C written once, all bf16 (the per-launch minimum the
+    PMC traffic is compared with)."""
+    launches, nbytes = 0, 0.0
+    for kind, n in calls:
+        tokens, w, layers = (arch.v_tokens, arch.v_width, arch.v_layers) if kind == "image" else (arch.ctx, arch.t_width, arch.t_layers)
+        m = n * tokens
+        if m <= 512:
+            continue                                     # the skinny kernel takes these
+        for nn, kk in ((3 * w, w), (w, w), (4 * w, w), (w, 4 * w)):
+            nbytes += layers * 2.0 * (m * kk + nn * kk + m * nn)
+        launches += 4 * layers
+    return launches, nbytes
+
+
 def gemm_flops_per_step_text(arch, batch):
     """The text towers' share of gemm_flops_per_step (2 * batch texts)."""
     return 2.0 * (2 * batch * arch.ctx) * arch.t_layers * (arch.t_width * 3 * arch.t_width + arch.t_width * arch.t_width + 2 * arch.t_width * 4 * arch.t_width)
@@ -166,16 +182,20 @@ def main():
     text_group = args.text_group or (engine.tile_friendly_batch(arch.ctx, arch.t_width, B, engine.MAX_TEXT_BATCH) if B == 255 else 2 * B)
     text_pool = torch.cat([q_ids, t_ids] * (-(-text_group // (2 * B))))[:text_group].contiguous()
 
+    all_calls = []                 # every encoder call of this process, in order: (kind, items)
+
     class Stepper:
         def __init__(self, e):
-            self.e, self.pending, self.images, self.texts = e, 0, 0, 0      # pooled texts; items encoded so far
+            self.e, self.pending, self.images, self.texts, self.calls = e, 0, 0, 0, all_calls      # pooled texts; items encoded so far; the process-wide call list
 
         def step(self):
             a = self.e.encode_image(pixels, normalize=True)
+            self.calls.append(("image", B))
             self.images += B
             self.pending += 2 * B
             while self.pending >= text_group:
                 self.e.encode_text(text_pool, normalize=True)
+                self.calls.append(("text", text_group))
                 self.pending -= text_group
                 self.texts += text_group
             return a
@@ -183,10 +203,12 @@ def main():
         def drain(self):
             if self.pending:
                 self.e.encode_text(text_pool[:self.pending], normalize=True)
+                self.calls.append(("text", self.pending))
                 self.texts += self.pending
                 self.pending = 0
 
         def check_outputs(self):            # the step's own items, for the oracle / cross-precision comparisons (untimed)
+            self.calls += [("image", B), ("text", B), ("text", B)]
             return (self.e.encode_image(pixels, normalize=True), self.e.encode_text(q_ids, normalize=True),
                     self.e.encode_text(t_ids, normalize=True))
 
@@ -418,6 +440,9 @@ def main():
             "rank_metrics_n8192_s": t_rank, "gpu_vs_oracle_min_cosine_images": cos_img, "gpu_vs_oracle_min_cosine_texts": cos_txt,
         }
 
+    # what the PMC passes of tools/profile_round.sh average over: every persistent-GEMM launch of this process
+    c_launches, c_bytes = gemm256u_census(arch, all_calls)
+    result["roofline"]["census"] = {"gemm256u_launches": c_launches, "algorithmic_bytes_per_launch": c_bytes / max(c_launches, 1)}
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
