@@ -284,7 +284,7 @@ def main():
     # attached only to the configuration it was measured for.
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-    if os.path.exists(tpath) and args.model == "ViT-L/14" and B == 255 and args.precision in ("bf16", "bf16-res16") and args.gemm_variant == 0:
+    if os.path.exists(tpath) and args.model == "ViT-L/14" and B == 255 and args.precision in ("bf16", "bf16-res16") and args.gemm_variant == 0 and not args.text_group:
         with open(tpath) as f:
             tj = json.load(f)
         traffic, traffic_source = tj.get("bytes_per_launch"), {k: tj.get(k) for k in ("profile", "round", "commit", "algorithmic_bytes_per_launch")}
