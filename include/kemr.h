@@ -219,7 +219,9 @@ int kemr_profile_end(double* ms_per_class, int64_t* launches_per_class, int ncla
 typedef enum kemr_epilogue {
     KEMR_EPI_BIAS_BF16 = 0,        /* C_bf16 = A.W^T + bias                                  */
     KEMR_EPI_BIAS_QGELU_BF16 = 1,  /* C_bf16 = quickgelu(A.W^T + bias)                       */
-    KEMR_EPI_BIAS_RESID_F32 = 2    /* X_f32 += A.W^T + bias   (in place on the residual)      */
+    KEMR_EPI_BIAS_RESID_F32 = 2,   /* X_f32 += A.W^T + bias   (in place on the residual)      */
+    KEMR_EPI_BIAS_RESADD_BF16 = 4  /* X_bf16 = bf16(bf16(A.W^T + bias) + X_bf16), in place; persistent 256 x 256 kernel only:
+                                      N % 256 == 0, m > 512, C with ceil256(m) rows                              */
 } kemr_epilogue;
 /* A bf16 [m_alloc, k] and C [m_alloc, n] with m_alloc = m rounded up to 256 rows (pad rows of A are read; pad rows of C
  * may be written by the bf16 epilogues), W bf16 [n, k], bias fp32 [n] */

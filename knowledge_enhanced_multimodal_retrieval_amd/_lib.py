@@ -28,6 +28,7 @@ PRECISIONS = {"bf16": PREC_BF16, "bf16-res16": PREC_BF16_RES16, "fp8": PREC_FP8,
 TOWER_VISION, TOWER_TEXT = 0, 1
 SIDE_QUERY, SIDE_GALLERY = 0, 1
 EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RESID_F32 = 0, 1, 2
+EPI_BIAS_RESADD_BF16 = 4
 
 
 class KemrCfg(C.Structure):

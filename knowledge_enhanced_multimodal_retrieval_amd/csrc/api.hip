@@ -481,7 +481,7 @@ extern "C" int kemr_profile_end(double* ms_per_class, int64_t* launches_per_clas
 extern "C" int kemr_op_gemm(const void* a_dev, const void* w_dev, const float* bias_dev, void* c_dev, int m, int n, int k,
                             int epilogue, void* stream) {
     if (!a_dev || !w_dev || !c_dev) KEMR_FAIL(KEMR_ERR_INVALID, "op_gemm: null argument");
-    if (epilogue < 0 || epilogue > KEMR_EPI_BIAS_RESID_F32) KEMR_FAIL(KEMR_ERR_INVALID, "op_gemm: bad epilogue %d", epilogue);
+    if (epilogue < 0 || (epilogue > KEMR_EPI_BIAS_RESID_F32 && epilogue != KEMR_EPI_BIAS_RESADD_BF16)) KEMR_FAIL(KEMR_ERR_INVALID, "op_gemm: bad epilogue %d", epilogue);
     GemmParams g{};
     g.A = (const bf16_t*)a_dev; g.lda = k; g.W = (const bf16_t*)w_dev; g.ldw = k; g.bias = bias_dev; g.C = c_dev; g.ldc = n;
     g.M = m; g.N = n; g.K = k;

@@ -107,7 +107,8 @@ enum GemmEpi : int {
     EPI_BIAS_BF16 = KEMR_EPI_BIAS_BF16,
     EPI_BIAS_QGELU_BF16 = KEMR_EPI_BIAS_QGELU_BF16,
     EPI_BIAS_RESID_F32 = KEMR_EPI_BIAS_RESID_F32,
-    EPI_PATCH_F32 = 3,     // X_f32[remap(m)] = acc + pos[1 + m % tokens_per_img]   (patch embedding)
+    EPI_PATCH_F32 = 3,
+    EPI_BIAS_RESADD_BF16 = KEMR_EPI_BIAS_RESADD_BF16,   // X_bf16 = bf16(bf16(A.W^T + bias) + X_bf16), in place (gemm256u only)     // X_f32[remap(m)] = acc + pos[1 + m % tokens_per_img]   (patch embedding)
 };
 struct GemmParams {
     const bf16_t* A;     // [m_alloc, lda] bf16, K contiguous

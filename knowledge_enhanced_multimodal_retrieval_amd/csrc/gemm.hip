@@ -181,6 +181,11 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     const bool can256 = p.N % 256 == 0 && p.K >= 128;
     const long tiles256 = (long)((p.M + 255) / 256) * (p.N / 256);
     const bool bf16_epi = epi == EPI_BIAS_BF16 || epi == EPI_BIAS_QGELU_BF16;
+    if (epi == EPI_BIAS_RESADD_BF16) {        // read-modify-write of the bf16 residual stream: only the persistent kernel has it
+        if (!(can256 && p.c_rows_padded && p.M > 512 && gemm256u_fits(p, 2)))
+            KEMR_FAIL(KEMR_ERR_INVALID, "gemm: the residual-add epilogue needs N %% 256 == 0, more than 512 rows and a row-padded C (M=%d N=%d K=%d)", p.M, p.N, p.K);
+        return launch_gemm256u(p, epi, stream);
+    }
     // a handful of rows (one or a few online queries): 6-24 tiles would leave the chip idle; split K inside the workgroup
     if (bf16_epi && p.c_rows_padded && (g_gemm_variant == 8 || (g_gemm_variant == 0 && p.M <= 512))) return launch_gemm_skinny(p, epi, stream);
 #ifdef KEMR_AB_VARIANTS      // earlier persistent generations, A/B timing from tools/ only (build.py --ab-variants)

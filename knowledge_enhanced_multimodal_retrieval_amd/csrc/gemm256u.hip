@@ -733,6 +733,31 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
                 }
             };
             u32x4 dA0, dA1, dB0, dB1;           // read-back of the pass in flight in each of the two areas
+            // EPI_BIAS_RESADD_BF16: the 16-byte chunks of the residual stream that the passes' stores will overwrite come in through
+            // a rolling window of four passes (loaded at the offsets the stores use); vmcnt retires loads and stores in order, so the
+            // wait in front of pass p's add counts what was issued behind its pair: the younger pairs and the older passes' stores.
+            constexpr bool RES = EPI == EPI_BIAS_RESADD_BF16;
+            u32x4 xr0[4], xr1[4];
+            unsigned xoff = voff;
+    #define KEMR_XLOAD(P)                                                                                                           \
+            do {                                                                                                                    \
+                if constexpr (RES) {                                                                                                \
+                    asm volatile("global_load_dwordx4 %0, %2, %4\n\tglobal_load_dwordx4 %1, %3, %4"                                  \
+                                 : "=&v"(xr0[(P) & 3]), "=&v"(xr1[(P) & 3]) : "v"(xoff), "v"(xoff + step8), "s"(ctile) : "memory"); \
+                    xoff += 2 * step8;                                                                                              \
+                }                                                                                                                   \
+            } while (0)
+            auto add8 = [](u32x4 d, u32x4 x) {          // bf16 x 8 + bf16 x 8 in fp32, rounded once (RNE)
+                u32x4 r;
+    #pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const f32x2_t a = {__uint_as_float(d[w] << 16), __uint_as_float(d[w] & 0xffff0000u)};
+                    const f32x2_t b = {__uint_as_float(x[w] << 16), __uint_as_float(x[w] & 0xffff0000u)};
+                    const f32x2_t c = a + b;
+                    r[w] = pack_bf16x2(c.x, c.y);
+                }
+                return r;
+            };
             // one pass through LDS: 4 writes of the packed quads, 2 reads of whole 16-byte chunks; area B is 8 KiB behind area A
     #define KEMR_LDS_PASS(D0, D1, OFF, OFF1)                                                                                        \
             asm volatile("ds_write_b64 %2, %6 offset:" #OFF "\n\tds_write_b64 %3, %7 offset:" #OFF "\n\tds_write_b64 %4, %8 offset:" #OFF "\n\t" \
@@ -744,6 +769,14 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             // launch evicts the A / W panels the K loops live on from L2 (round 1, encoder shapes: plain stores +27 % time on QKV,
             // +17 % on fc1 over no stores at all; `nt` stores +0 % / +6 %; `sc1` write-through +13 %).  Exactly 16 stores per lane
             // and tile: the vmcnt bookkeeping in the header counts them.  dbg 1 / 4 (DBG instantiation, tools/): stores dropped / plain.
+    #define KEMR_RES_ADD(D0, D1, P, VM)                                                                                             \
+            do {                                                                                                                    \
+                if constexpr (RES) {                                                                                                \
+                    asm volatile("s_waitcnt vmcnt(" #VM ")" : "+v"(xr0[(P) & 3]), "+v"(xr1[(P) & 3]) :: "memory");                  \
+                    D0 = add8(D0, xr0[(P) & 3]);                                                                                    \
+                    D1 = add8(D1, xr1[(P) & 3]);                                                                                    \
+                }                                                                                                                   \
+            } while (0)
     #define KEMR_STORE_PASS(D0, D1, WAIT)                                                                                           \
             do {                                                                                                                    \
                 asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" : "+v"(D0), "+v"(D1) :: "memory");                                      \
@@ -770,6 +803,27 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
                 pack(acc[6]); KEMR_STORE_PASS(dA0, dA1, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
                 pack(acc[7]); KEMR_STORE_PASS(dA0, dA1, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
                 KEMR_STORE_PASS(dA0, dA1, 0);
+            } else if constexpr (RES) {
+                // VMEM order: L0 L1 L2 L3 | S0 L4 | S1 L5 | S2 L6 | S3 L7 | S4 | S5 | S6 | S7 (a pair = 2 loads, a pass = 2 stores)
+                KEMR_XLOAD(0); KEMR_XLOAD(1); KEMR_XLOAD(2); KEMR_XLOAD(3);
+                pack(acc[0]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                pack(acc[1]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(dA0), "+v"(dA1) :: "memory"); KEMR_RES_ADD(dA0, dA1, 0, 6);
+                KEMR_STORE_PASS(dA0, dA1, 6); KEMR_XLOAD(4); pack(acc[2]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(dB0), "+v"(dB1) :: "memory"); KEMR_RES_ADD(dB0, dB1, 1, 8);
+                KEMR_STORE_PASS(dB0, dB1, 6); KEMR_XLOAD(5); pack(acc[3]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(dA0), "+v"(dA1) :: "memory"); KEMR_RES_ADD(dA0, dA1, 2, 10);
+                KEMR_STORE_PASS(dA0, dA1, 6); KEMR_XLOAD(6); pack(acc[4]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(dB0), "+v"(dB1) :: "memory"); KEMR_RES_ADD(dB0, dB1, 3, 12);
+                KEMR_STORE_PASS(dB0, dB1, 6); KEMR_XLOAD(7); pack(acc[5]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(dA0), "+v"(dA1) :: "memory"); KEMR_RES_ADD(dA0, dA1, 4, 12);
+                KEMR_STORE_PASS(dA0, dA1, 6); pack(acc[6]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(dB0), "+v"(dB1) :: "memory"); KEMR_RES_ADD(dB0, dB1, 5, 10);
+                KEMR_STORE_PASS(dB0, dB1, 6); pack(acc[7]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(dA0), "+v"(dA1) :: "memory"); KEMR_RES_ADD(dA0, dA1, 6, 8);
+                KEMR_STORE_PASS(dA0, dA1, 6);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dB0), "+v"(dB1) :: "memory"); KEMR_RES_ADD(dB0, dB1, 7, 6);
+                KEMR_STORE_PASS(dB0, dB1, 0);
             } else {
             pack(acc[0]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
             pack(acc[1]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
@@ -785,6 +839,8 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             if (CONC && wr == 1) __builtin_amdgcn_s_barrier();
     #undef KEMR_LDS_PASS
     #undef KEMR_STORE_PASS
+    #undef KEMR_RES_ADD
+    #undef KEMR_XLOAD
         }
         stamp(9);
     }
@@ -1030,6 +1086,7 @@ int launch_gemm256u(const GemmParams& p, int epi, hipStream_t stream) {
     switch (epi) {
         case EPI_BIAS_BF16:       return launch256u<EPI_BIAS_BF16, false>(p, stream);
         case EPI_BIAS_QGELU_BF16: return launch256u<EPI_BIAS_QGELU_BF16, false>(p, stream);
+        case EPI_BIAS_RESADD_BF16: return launch256u_a<EPI_BIAS_RESADD_BF16, false, false, false>(p, stream);
     }
     KEMR_FAIL(KEMR_ERR_INVALID, "gemm256u: epilogue %d is not a bf16-store epilogue", epi);
 }

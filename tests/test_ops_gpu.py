@@ -208,6 +208,32 @@ def test_layernorm_fp8_output(device):
         assert float(((got - ref).abs() - ref.abs() / 16).max()) < 2e-3
 
 
+@pytest.mark.parametrize("m,n,k", [(65535, 1024, 1024), (19635, 768, 3072), (1000, 256, 128), (65535, 1024, 4096)])
+def test_gemm_residual_add_epilogue(device, m, n, k):
+    """EPI_BIAS_RESADD_BF16: the persistent kernel reads the bf16 residual tile its stores overwrite (a rolling window of loads
+    with counted vmcnt) and writes bf16(bf16(A.W^T + bias) + x): bit-identical to the store-only epilogue followed by a bf16
+    add, on shapes with one to many tiles per CU and a ragged last row tile."""
+    g = torch.Generator(device=device).manual_seed(m + n + k)
+    ma = (m + 255) // 256 * 256
+    a = torch.randn(ma, k, generator=g, device=device).to(torch.bfloat16)
+    w = (torch.randn(n, k, generator=g, device=device) * k ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(n, generator=g, device=device)
+    x = (torch.randn(ma, n, generator=g, device=device) * 3).to(torch.bfloat16)
+    engine.set_gemm_variant(7)                               # the reference through the same kernel (small shapes go elsewhere)
+    try:
+        delta = engine.op_gemm(a, w, bias, m, _lib.EPI_BIAS_BF16)
+    finally:
+        engine.set_gemm_variant(0)
+    want = (delta[:m].float() + x[:m].float()).to(torch.bfloat16)
+    got = x.clone()
+    for _ in range(2):                                       # second round on top of the first: in-place accumulation
+        engine.op_gemm(a, w, bias, m, _lib.EPI_BIAS_RESADD_BF16, c=got)
+        assert torch.equal(got[:m], want)
+        want = (delta[:m].float() + want.float()).to(torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        engine.op_gemm(a[:256], w, bias, 100, _lib.EPI_BIAS_RESADD_BF16, c=x[:256].clone())      # too few rows for the persistent kernel
+
+
 def test_gemm_rejects_bad_shapes(device):
     a = torch.zeros(256, 96, dtype=torch.bfloat16, device=device)
     w = torch.zeros(128, 96, dtype=torch.bfloat16, device=device)

@@ -10,7 +10,7 @@ from knowledge_enhanced_multimodal_retrieval_amd import engine, _lib
 dev = torch.device("cuda:0")
 B = 255
 shapes = [("v.qkv", B * 257, 3072, 1024, 0), ("v.out", B * 257, 1024, 1024, 0), ("v.fc1", B * 257, 4096, 1024, 1), ("v.fc2", B * 257, 1024, 4096, 0),
-          ("t.qkv", B * 77, 2304, 768, 0), ("t.fc1", B * 77, 3072, 768, 1)]
+          ("t.qkv", B * 77, 2304, 768, 0), ("t.fc1", B * 77, 3072, 768, 1), ("t851.out", 851 * 77, 768, 768, 0), ("t851.fc2", 851 * 77, 768, 3072, 0)]
 g = torch.Generator(device=dev).manual_seed(0)
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 orders = [0, 3]          # 0: N fastest; 3: column groups of 4 tiles
@@ -61,6 +61,24 @@ for name, m, n, k, epi in shapes:
                 out.setdefault(o, []).append(e0.elapsed_time(e1) / 300 * 1e3)
         fl = 2.0 * m * n * k
         print("ab", name, {o: "%.1f us %.0f TF (%s)" % (sorted(t)[len(t) // 2], fl / sorted(t)[len(t) // 2] / 1e6, " ".join("%.0f" % x for x in t)) for o, t in out.items()}, flush=True)
+    if what in ("res",) and epi == 0 and n <= 1024:
+        # residual-add epilogue (reads the bf16 x tile it overwrites) against the store-only epilogue, sustained, interleaved
+        x = (torch.randn(ma, n, generator=g, device=dev) * 3).to(torch.bfloat16)
+        out = {}
+        for rnd in range(3):
+            for label, e, cc in (("store", 0, c), ("resadd", 4, x)):
+                engine.set_gemm_variant(variant(3, conc=2))
+                fn = lambda: engine.op_gemm(a, w, bias, m, e, c=cc)
+                for _ in range(400):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(300):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                out.setdefault(label, []).append(e0.elapsed_time(e1) / 300 * 1e3)
+        print("res", name, {o: "%.1f us (%s)" % (sorted(t)[1], " ".join("%.0f" % v for v in t)) for o, t in out.items()}, flush=True)
     if what in ("conc",):
         # both halves' epilogues in the same barrier interval (conc = 1) against one after the other (0): parity, then
         # sustained interleaved timing, then the stamp profile of the stamped instantiation
