@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--image-slice", type=int, default=0, help="experiment: images per encoder launch (default: the engine's 255)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="A/B only: force a GEMM tile variant (0 = the library's choice)")
     ap.add_argument("--text-group", type=int, default=0, help="texts per encoder call (0 = engine.tile_friendly_batch: 851 for ViT-L/14; 255 = one call per text column and step, round 1 / early round 2)")
+    ap.add_argument("--resadd", type=int, default=-1, help="A/B: 1 / 0 = residual add inside the out-proj / fc2 epilogues on / off (default: the library's setting)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sim", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp8 / bf16-res16 sub-results (two more engines, ~20 steps each)")
@@ -168,6 +169,8 @@ def main():
         engine.MAX_IMAGE_BATCH = args.image_slice
     if args.gemm_variant:
         engine.set_gemm_variant(args.gemm_variant)
+    if args.resadd >= 0:
+        engine.set_gemm_variant((args.resadd + 1) << 28)
     eng.load_state_dict(random_weights(arch, seed=0))
 
     g = torch.Generator().manual_seed(1234 + rank)

@@ -347,12 +347,26 @@ int carve(Workspace& w, void* base, size_t bytes, int width, int tokens, int bat
 // as bf16 into `delta` / `delta2` (store-only epilogues) and the LayerNorms apply the updates while they read x anyway:
 // ln_2 normalises x + delta without writing x; the next block's ln_1 writes x += delta + delta2 once and normalises it.
 // On return both deltas of the last block are still pending; the caller's tail adds them.
-int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, int fp8, hipStream_t s) {
+//
+// g_resadd (bf16 residual stream, calls the persistent GEMM takes whole): the out-proj and fc2 epilogues read the x tile they
+// overwrite and add it (EPI_BIAS_RESADD_BF16), both LayerNorms read x and write h only: 8 instead of 16 bytes per element and
+// layer in the LayerNorms against 28 kB more per output tile in those two GEMMs.  x is then rounded to bf16 twice per
+// layer (after the attention update and after the MLP update) instead of once.  *pending = deltas left for the tail.
+int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, int fp8, hipStream_t s, bool* pending) {
     const int W = t.width, M = batch * t.tokens;
     const bool fq = fp8 & 1, f1 = fp8 & 2;          // LayerNorm output = A operand of QKV / fc1: e4m3 where that GEMM runs in fp8
+    bool resadd = g_resadd && w.x_dtype == KEMR_BF16 && M > 512 && W % 256 == 0;
+    if (resadd) {
+        GemmParams a{}, b{};
+        a.M = b.M = M; a.N = b.N = W; a.K = W; b.K = 4 * W; a.lda = W; b.lda = 4 * W; a.ldw = W; b.ldw = 4 * W; a.ldc = b.ldc = W;
+        a.c_rows_padded = b.c_rows_padded = 1;
+        resadd = gemm256u_fits(a, 2) && gemm256u_fits(b, 2);
+    }
+    *pending = !resadd && t.layers > 0;
     for (int l = 0; l < t.layers; ++l) {
         const LayerW& L = t.layer[l];
-        KEMR_TRY(launch_layernorm(w.x, w.x_dtype, l ? w.delta : nullptr, l ? w.delta2 : nullptr, 1, L.ln1_g, L.ln1_b, w.h, M, W, fq ? KEMR_FP8 : KEMR_BF16, s));
+        if (resadd) KEMR_TRY(launch_layernorm(w.x, w.x_dtype, nullptr, nullptr, 0, L.ln1_g, L.ln1_b, w.h, M, W, fq ? KEMR_FP8 : KEMR_BF16, s));
+        else KEMR_TRY(launch_layernorm(w.x, w.x_dtype, l ? w.delta : nullptr, l ? w.delta2 : nullptr, 1, L.ln1_g, L.ln1_b, w.h, M, W, fq ? KEMR_FP8 : KEMR_BF16, s));
         GemmParams g{};
         g.M = M;
         g.c_rows_padded = 1;       // every workspace buffer has ceil256(M) rows
@@ -365,9 +379,9 @@ int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, int f
             KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
         }
         KEMR_TRY(launch_attention(w.big, w.h, batch, t.tokens, W, causal, s));
-        g.A = w.h; g.lda = W; g.W = L.wo; g.ldw = W; g.bias = L.bo; g.C = w.delta; g.ldc = W; g.N = W; g.K = W;
-        KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
-        KEMR_TRY(launch_layernorm(w.x, w.x_dtype, w.delta, nullptr, 0, L.ln2_g, L.ln2_b, w.h, M, W, f1 ? KEMR_FP8 : KEMR_BF16, s));
+        g.A = w.h; g.lda = W; g.W = L.wo; g.ldw = W; g.bias = L.bo; g.C = resadd ? w.x : (void*)w.delta; g.ldc = W; g.N = W; g.K = W;
+        KEMR_TRY(launch_gemm(g, resadd ? EPI_BIAS_RESADD_BF16 : EPI_BIAS_BF16, s));
+        KEMR_TRY(launch_layernorm(w.x, w.x_dtype, resadd ? nullptr : w.delta, nullptr, 0, L.ln2_g, L.ln2_b, w.h, M, W, f1 ? KEMR_FP8 : KEMR_BF16, s));
         g.A = w.h; g.lda = W; g.W = L.w1; g.ldw = W; g.bias = L.b1; g.C = w.big; g.ldc = 4 * W; g.N = 4 * W; g.K = W;
         if (f1) {
             g.W = (const bf16_t*)L.w18; g.wscale = L.s1;
@@ -376,8 +390,8 @@ int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, int f
         } else {
             KEMR_TRY(launch_gemm(g, EPI_BIAS_QGELU_BF16, s));
         }
-        g.A = w.big; g.lda = 4 * W; g.W = L.w2; g.ldw = 4 * W; g.bias = L.b2; g.C = w.delta2; g.ldc = W; g.N = W; g.K = 4 * W;
-        KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+        g.A = w.big; g.lda = 4 * W; g.W = L.w2; g.ldw = 4 * W; g.bias = L.b2; g.C = resadd ? w.x : (void*)w.delta2; g.ldc = W; g.N = W; g.K = 4 * W;
+        KEMR_TRY(launch_gemm(g, resadd ? EPI_BIAS_RESADD_BF16 : EPI_BIAS_BF16, s));
     }
     return KEMR_OK;
 }
@@ -408,8 +422,8 @@ extern "C" int kemr_encode_image(kemr_model* m, const float* pixels_dev, int bat
     KEMR_TRY(launch_gemm(g, EPI_PATCH_F32, s));
     KEMR_TRY(launch_cls_rows(w.x32, m->cls, m->vpos, batch, T, W, s));
     KEMR_TRY(launch_layernorm(w.x32, KEMR_F32, nullptr, nullptr, 0, m->lnpre_g, m->lnpre_b, w.x, batch * T, W, w.x_dtype, s));
-    KEMR_TRY(run_blocks(m->vis, w, batch, 0, m->fp8, s));
-    const bool vb = m->vis.layers > 0;
+    bool vb = false;
+    KEMR_TRY(run_blocks(m->vis, w, batch, 0, m->fp8, s, &vb));
     KEMR_TRY(launch_tail(w.x, w.x_dtype, vb ? w.delta : nullptr, vb ? w.delta2 : nullptr, nullptr, batch, T, W, m->lnpost_g, m->lnpost_b, m->vproj, m->cfg.embed_dim, normalize, out_dev, s));
     return KEMR_OK;
 }
@@ -425,8 +439,8 @@ extern "C" int kemr_encode_text(kemr_model* m, const int32_t* ids_dev, int batch
     Workspace w;
     KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, T, batch, m->res_dtype));
     KEMR_TRY(launch_text_embed(ids_dev, m->tok, m->tpos, w.x, w.x_dtype, batch, T, W, m->cfg.vocab, s));
-    KEMR_TRY(run_blocks(m->txt, w, batch, 1, m->fp8, s));
-    const bool tb = m->txt.layers > 0;
+    bool tb = false;
+    KEMR_TRY(run_blocks(m->txt, w, batch, 1, m->fp8, s, &tb));
     KEMR_TRY(launch_tail(w.x, w.x_dtype, tb ? w.delta : nullptr, tb ? w.delta2 : nullptr, ids_dev, batch, T, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s));
     return KEMR_OK;
 }
@@ -435,6 +449,7 @@ extern "C" int kemr_set_gemm_variant(int variant) {
     g_gemm_dbg = (variant >> 8) & 0xff;   // bits 8..15: timing-experiment flags (tools/ only)
     if ((variant >> 16) & 0xf) g_gemm_order = ((variant >> 16) & 0xf) - 1;
     if ((variant >> 24) & 0xf) g_attn_waves = ((variant >> 24) & 0xf) - 1;   // bits 24..27: attention waves per workgroup for T = 257 (+ 1; 0 / 4 default, 6) (tools/ only)
+    if ((variant >> 28) & 0x3) g_resadd = ((variant >> 28) & 0x3) - 1;       // bits 28..29: residual add in the out-proj / fc2 epilogues (+ 1) (tools / tests)
     if ((variant >> 20) & 0x3) g_gemm_conc = ((variant >> 20) & 0x3) - 1;     // bits 20..21: gemm256u concurrent epilogues (0 never / 1 always / 2 QuickGELU only) + 1 (tools/ only; 0 keeps the current setting)   // bits 16..19: gemm256u tile order + 1 (tools/ only; 0 keeps the current one)
     variant &= 0xff;
     if (variant < 0 || variant > 9) KEMR_FAIL(KEMR_ERR_INVALID, "set_gemm_variant: 0 auto, 1 = 128x128, 2 = 256x256 lockstep, 3 = 256x256 staggered, 4 / 5 = persistent 8-wave (4 / 2 phases per K-tile), 6 = persistent 4-wave, 7 = persistent 8-wave with one K-tile pipeline across tiles, 8 = skinny-M split-K, 9 = persistent 4-wave with register-staged operands");

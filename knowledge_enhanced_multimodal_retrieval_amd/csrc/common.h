@@ -141,6 +141,7 @@ struct GemmParams {
 };
 extern int g_gemm_dbg;
 extern int g_gemm_order;
+extern int g_resadd;        // api.hip: residual add inside the out-proj / fc2 epilogues for bf16 residual streams
 extern int g_attn_waves;    // attention.hip (tools)
 extern int g_gemm_conc;     // gemm256u: both wave halves run their epilogues in the same barrier interval (0 never, 1 always, 2 = QuickGELU epilogue only)
 int gemm_read_stamps(unsigned* host_out, int n_words);

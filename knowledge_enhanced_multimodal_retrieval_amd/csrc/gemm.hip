@@ -169,7 +169,8 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
 int g_gemm_variant = 0;
 int g_gemm_dbg = 0;
 int g_gemm_order = 3;
-int g_gemm_conc = 2;      // gemm256u tile order: column groups of 4 tiles (tools/bench_gemm_r2.py: fc1 -1 %, QKV -0.4 % against N fastest)
+int g_gemm_conc = 2;
+int g_resadd = 0;      // gemm256u tile order: column groups of 4 tiles (tools/bench_gemm_r2.py: fc1 -1 %, QKV -0.4 % against N fastest)
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     if (p.M <= 0) return KEMR_OK;
