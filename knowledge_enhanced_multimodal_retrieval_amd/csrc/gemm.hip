@@ -13,6 +13,7 @@
 // v1 structure ("minimum 2-phase" of cdna_hip_programming.md T3+T4): double-buffered LDS, the loads of
 // K-tile t+1 are issued before the MFMAs of K-tile t, one vmcnt(0)+barrier per K-tile.
 #include "common.h"
+#include <cstdlib>
 
 namespace kemr {
 
@@ -170,7 +171,14 @@ int g_gemm_variant = 0;
 int g_gemm_dbg = 0;
 int g_gemm_order = 3;
 int g_gemm_conc = 2;
-int g_resadd = 0;      // gemm256u tile order: column groups of 4 tiles (tools/bench_gemm_r2.py: fc1 -1 %, QKV -0.4 % against N fastest)
+// Residual add inside the out-proj / fc2 epilogues for bf16 residual streams (api.hip run_blocks): on unless KEMR_RESADD=0
+// (measured, round 2, same device: 16 690 -> 17 300 items/s, LayerNorm 5.25 -> 2.75 ms, GEMMs 34.9 -> 35.9 ms per step;
+// image 1 - cos against the fp32 oracle 4.2e-5 -> 8.0e-5: x is rounded twice per layer instead of once)
+static int env_flag(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) != 0 : dflt;
+}
+int g_resadd = env_flag("KEMR_RESADD", 1);      // gemm256u tile order: column groups of 4 tiles (tools/bench_gemm_r2.py: fc1 -1 %, QKV -0.4 % against N fastest)
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     if (p.M <= 0) return KEMR_OK;

@@ -171,6 +171,27 @@ def test_fp8_encoders_match_oracle(device, name, nimg, ntxt, precision, tol):
     assert float((1 - ci).max()) < tol and float((1 - ct).max()) < tol
 
 
+def test_residual_fusion_switch(device):
+    """bf16 residual stream: residual add inside the out-proj / fc2 epilogues (default) against the store-only epilogues +
+    LayerNorm updates: both inside the path's bar against the oracle, close to each other, and the switch really switches."""
+    arch, sd, eng = _engine("ViT-B/32", device, precision="bf16-res16")
+    oa = clip_ref.ARCHS["ViT-B/32"]
+    g = torch.Generator().manual_seed(77)
+    px = torch.randn(40, 3, arch.image_size, arch.image_size, generator=g)            # 2 000 token rows: the persistent GEMM's side of the switch
+    ids = clip_ref.synthetic_ids(oa, 24)
+    ref_i, ref_t = clip_ref.encode_image(sd, oa, px[:4]), clip_ref.encode_text(sd, oa, ids[:4])
+    outs = {}
+    try:
+        for on in (True, False):
+            engine.set_residual_fusion(on)
+            outs[on] = (eng.encode_image(px.to(device)).cpu(), eng.encode_text(ids.to(device)).cpu())
+            assert float((1 - _cos(outs[on][0][:4], ref_i)).max()) < COS_TOL and float((1 - _cos(outs[on][1][:4], ref_t)).max()) < COS_TOL
+    finally:
+        engine.set_residual_fusion(True)
+    assert not torch.equal(outs[True][0], outs[False][0])
+    assert float((1 - _cos(outs[True][0], outs[False][0])).max()) < 3e-4 and float((1 - _cos(outs[True][1], outs[False][1])).max()) < 3e-4
+
+
 def test_fp8_recall_at_10_within_0p2_percent_of_bf16(device):
     """Retrieval with a noisy copy of every gallery image as the query, at three noise levels (bf16 Recall@10 about 99.8 /
     88 / 58 %): the "fp8" engine's Recall@10 must stay within 0.2 percentage points of the bf16 engine's on the same inputs
@@ -209,6 +230,8 @@ def test_fp8_recall_at_10_within_0p2_percent_of_bf16(device):
         # Inside config 5's bar only where recall is saturated; bounded and recorded elsewhere, like "fp8-mlp".
         # (records, not bars: two builds of this round measured 0.14 / 0.35 and 0.31 / 0.27 for bf16-res16, 0.36 / 0.28 and
         # 0.42 / 0.23 for fp8-res16 -- a change of the softmax summation order moves them by 0.1)
-        assert abs(ref - res[("bf16-res16", lvl)]["T2I_R@10"]) <= (0.2 if lvl == 1.5 else 0.6) + 1e-9
-        assert abs(ref - res[("fp8-res16", lvl)]["T2I_R@10"]) <= (0.2 if lvl == 1.5 else 0.6) + 1e-9
+        # With the residual add inside the out-proj / fc2 epilogues (the default since the end of round 2: x rounded twice per
+        # layer) the records are 0.58 / 0.46 (bf16-res16) and 0.73 / 0.49 (fp8-res16); KEMR_RESADD=0 gives the figures above.
+        assert abs(ref - res[("bf16-res16", lvl)]["T2I_R@10"]) <= (0.2 if lvl == 1.5 else 1.0) + 1e-9
+        assert abs(ref - res[("fp8-res16", lvl)]["T2I_R@10"]) <= (0.2 if lvl == 1.5 else 1.0) + 1e-9
         assert abs(ref - res[("fp8-mlp", lvl)]["T2I_R@10"]) <= (0.3 if lvl == 1.5 else 2.0) + 1e-9      # 0.19 / 0.21 at the saturated level: at the bar, not inside it
