@@ -105,15 +105,15 @@ def gemm_flops_per_step(arch, batch):
 def gemm256u_census(arch, calls):
     """(launches, algorithmic bytes) of the persistent-GEMM launches behind a list of encoder calls [(kind, items)]: per layer
     QKV, out-proj, fc1, fc2 with A + W read once and C written once, all bf16 (the per-launch minimum the
-    PMC traffic is compared with)."""
+    PMC traffic is compared with); with the residual add in the epilogue the out-proj and fc2 launches read their C tile too."""
     launches, nbytes = 0, 0.0
-    for kind, n in calls:
+    for kind, n, resadd in calls:
         tokens, w, layers = (arch.v_tokens, arch.v_width, arch.v_layers) if kind == "image" else (arch.ctx, arch.t_width, arch.t_layers)
         m = n * tokens
         if m <= 512:
             continue                                     # the skinny kernel takes these
         for nn, kk in ((3 * w, w), (w, w), (4 * w, w), (w, 4 * w)):
-            nbytes += layers * 2.0 * (m * kk + nn * kk + m * nn)
+            nbytes += layers * 2.0 * (m * kk + nn * kk + m * nn + (m * nn if (resadd and nn == w) else 0))
         launches += 4 * layers
     return launches, nbytes
 
@@ -171,6 +171,8 @@ def main():
         engine.set_gemm_variant(args.gemm_variant)
     if args.resadd >= 0:
         engine.set_gemm_variant((args.resadd + 1) << 28)
+    # residual add inside the out-proj / fc2 epilogues: the library's default for bf16 residual streams (KEMR_RESADD=0 turns it off)
+    resadd_on = args.precision.endswith("res16") and bool(args.resadd if args.resadd >= 0 else int(os.environ.get("KEMR_RESADD", "1") or "1"))
     eng.load_state_dict(random_weights(arch, seed=0))
 
     g = torch.Generator().manual_seed(1234 + rank)
@@ -188,17 +190,18 @@ def main():
     all_calls = []                 # every encoder call of this process, in order: (kind, items)
 
     class Stepper:
-        def __init__(self, e):
+        def __init__(self, e, resadd):
+            self.resadd = bool(resadd)
             self.e, self.pending, self.images, self.texts, self.calls = e, 0, 0, 0, all_calls      # pooled texts; items encoded so far; the process-wide call list
 
         def step(self):
             a = self.e.encode_image(pixels, normalize=True)
-            self.calls.append(("image", B))
+            self.calls.append(("image", B, self.resadd))
             self.images += B
             self.pending += 2 * B
             while self.pending >= text_group:
                 self.e.encode_text(text_pool, normalize=True)
-                self.calls.append(("text", text_group))
+                self.calls.append(("text", text_group, self.resadd))
                 self.pending -= text_group
                 self.texts += text_group
             return a
@@ -206,16 +209,16 @@ def main():
         def drain(self):
             if self.pending:
                 self.e.encode_text(text_pool[:self.pending], normalize=True)
-                self.calls.append(("text", self.pending))
+                self.calls.append(("text", self.pending, self.resadd))
                 self.texts += self.pending
                 self.pending = 0
 
         def check_outputs(self):            # the step's own items, for the oracle / cross-precision comparisons (untimed)
-            self.calls += [("image", B), ("text", B), ("text", B)]
+            self.calls += [("image", B, self.resadd), ("text", B, self.resadd), ("text", B, self.resadd)]
             return (self.e.encode_image(pixels, normalize=True), self.e.encode_text(q_ids, normalize=True),
                     self.e.encode_text(t_ids, normalize=True))
 
-    main_steps = Stepper(eng)
+    main_steps = Stepper(eng, resadd_on)
     step, drain = main_steps.step, main_steps.drain
 
     def barrier():
@@ -266,20 +269,25 @@ def main():
     # ------------------------------------------------------------------ roofline: per-class hipEvent timing
     L = _lib.lib()
     prof_steps = 10                                  # whole text groups only inside the profiled region; the rest drains after it
-    i0, t0_ = main_steps.images, main_steps.texts
-    _lib.check(L.kemr_profile_begin(4096 * prof_steps))
-    for _ in range(prof_steps):
-        step()
-    ms = (C.c_double * 5)()
-    cnt = (C.c_int64 * 5)()
-    _lib.check(L.kemr_profile_end(ms, cnt, 5))
-    n_img, n_txt = main_steps.images - i0, main_steps.texts - t0_
-    drain()
     f_step, _ = gemm_flops_per_step(arch, B)
     f_txt = gemm_flops_per_step_text(arch, B)
-    gemm_flops = (f_step - f_txt) * n_img / B + f_txt * n_txt / (2 * B)          # of what the region actually launched, per region
-    gemm_flops /= prof_steps
-    gemm_ms, gemm_n = ms[0] / prof_steps, cnt[0] / prof_steps
+
+    def profile_region(st):
+        """10 steps of `st` under the library's per-class hipEvent timing -> (ms per class and step, GEMM launches per step, GEMM flops per step)."""
+        i0, t0_ = st.images, st.texts
+        _lib.check(L.kemr_profile_begin(4096 * prof_steps))
+        for _ in range(prof_steps):
+            st.step()
+        ms_ = (C.c_double * 5)()
+        cnt_ = (C.c_int64 * 5)()
+        _lib.check(L.kemr_profile_end(ms_, cnt_, 5))
+        n_img, n_txt = st.images - i0, st.texts - t0_
+        st.drain()
+        fl = ((f_step - f_txt) * n_img / B + f_txt * n_txt / (2 * B)) / prof_steps      # of what the region actually launched
+        return [m_ / prof_steps for m_ in ms_], cnt_[0] / prof_steps, fl
+
+    ms, gemm_n, gemm_flops = profile_region(main_steps)
+    gemm_ms = ms[0]
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
     # L2-miss (fabric) bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes of this command
     # (tools/profile_round.sh <tag> pmc: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), committed under
@@ -287,7 +295,7 @@ def main():
     # attached only to the configuration it was measured for.
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-    if os.path.exists(tpath) and args.model == "ViT-L/14" and B == 255 and args.precision in ("bf16", "bf16-res16") and args.gemm_variant == 0 and not args.text_group:
+    if os.path.exists(tpath) and args.model == "ViT-L/14" and B == 255 and args.precision == "bf16-res16" and resadd_on and args.gemm_variant == 0 and not args.text_group:
         with open(tpath) as f:
             tj = json.load(f)
         traffic, traffic_source = tj.get("bytes_per_launch"), {k: tj.get(k) for k in ("profile", "round", "commit", "algorithmic_bytes_per_launch")}
@@ -298,8 +306,8 @@ def main():
         "launches_per_step": round(gemm_n, 1), "avg_launch_us": 1e3 * gemm_ms / max(gemm_n, 1),
         "flops_per_launch": gemm_flops / max(gemm_n, 1),
     }
-    result["kernel_ms_per_step"] = {"gemm": ms[0] / prof_steps, "layernorm": ms[1] / prof_steps,
-                                    "attention": ms[2] / prof_steps, "embed_tail": ms[3] / prof_steps}
+    result["kernel_ms_per_step"] = {"gemm": ms[0], "layernorm": ms[1], "attention": ms[2], "embed_tail": ms[3]}
+    result["config"]["residual_add_in_gemm_epilogue"] = resadd_on
 
     # ------------------------------------------------------------------ similarity + top-10 on the 43k gallery
     if not args.no_sim:
@@ -382,7 +390,7 @@ def main():
             e2 = engine.ClipEngine(arch, dev, precision=prec)
             e2.load_state_dict(random_weights(arch, seed=0))
 
-            s2 = Stepper(e2)
+            s2 = Stepper(e2, resadd_on and prec.endswith("res16"))
             for _ in range(3):
                 s2.step()
             s2.drain()
@@ -404,6 +412,29 @@ def main():
                             "min_cosine_vs_default_image_query_target": cos}
             del e2
         result["other_precisions"] = extras
+        if resadd_on:
+            # the same engine with the store-only epilogues (updates applied by the LayerNorms): the GEMM class then holds GEMM
+            # work only, which is the configuration the GEMM's own roofline fraction is best read on
+            engine.set_residual_fusion(False)
+            s3 = Stepper(eng, False)
+            for _ in range(3):
+                s3.step()
+            s3.drain()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                s3.step()
+            s3.drain()
+            barrier()
+            dt = time.perf_counter() - t1
+            ms3, n3, fl3 = profile_region(s3)
+            engine.set_residual_fusion(True)
+            a3 = fl3 / (ms3[0] * 1e-3) / 1e12
+            result["roofline_store_only_epilogues"] = {
+                "config": "KEMR_RESADD=0: out-proj / fc2 store deltas, the LayerNorms apply them (round 2's earlier default)",
+                "items_per_s": 3 * B * world * 20 / dt, "bound": "mfma", "achieved": a3, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": a3 / PEAK_BF16_TFLOPS, "launches_per_step": round(n3, 1),
+                "kernel_ms_per_step": {"gemm": ms3[0], "layernorm": ms3[1], "attention": ms3[2], "embed_tail": ms3[3]}}
 
     # ------------------------------------------------------------------ CPU baseline (oracle, bounded sample)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
