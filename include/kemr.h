@@ -48,6 +48,8 @@ typedef enum kemr_dtype { KEMR_F32 = 0, KEMR_BF16 = 1, KEMR_I32 = 2, KEMR_FP8 = 
  * KEMR_PREC_BF16_RES16: as above with the residual stream stored as bf16 between layers (what fp16/bf16 CLIP inference
  *                       does everywhere); LayerNorm statistics and the residual add stay fp32.  8 instead of 12 bytes
  *                       of HBM traffic per residual element and LayerNorm, and 16 instead of 18 workspace bytes.
+ *                       For calls of more than 512 token rows the residual add runs inside the out-proj / fc2 GEMM epilogues
+ *                       unless the environment holds KEMR_RESADD=0 (x is then rounded once per layer instead of twice, -3.7 %).
  * KEMR_PREC_FP8:        BASELINE config 5.  The QKV GEMMs (24 % of the FLOPs) run on fp8 e4m3 operands with the block-scaled
  *                       MFMA (K = 128 per instruction, twice the bf16 rate): ln_1 writes its output as e4m3 (unit scale,
  *                       saturating), the weights are quantised per output channel at finalize, the scale is applied to the
