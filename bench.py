@@ -113,7 +113,9 @@ def gemm256u_census(arch, calls):
         if m <= 512:
             continue                                     # the skinny kernel takes these
         for nn, kk in ((3 * w, w), (w, w), (4 * w, w), (w, 4 * w)):
-            nbytes += layers * 2.0 * (m * kk + nn * kk + m * nn + (m * nn if (resadd and nn == w) else 0))
+            # resadd: 0 = store-only bf16 C; 2 / 4 = the out-proj / fc2 launches read and write their C tile in place as bf16 / fp32
+            c_bytes = 2.0 * m * nn if not (resadd and nn == w) else 2.0 * resadd * m * nn
+            nbytes += layers * (2.0 * (m * kk + nn * kk) + c_bytes)
         launches += 4 * layers
     return launches, nbytes
 
@@ -131,7 +133,7 @@ def main():
     ap.add_argument("--batch", type=int, default=255, help="gallery items per rank per step")
     ap.add_argument("--model", default="ViT-L/14")
     ap.add_argument("--precision", default=_lib.DEFAULT_PRECISION, choices=["bf16", "bf16-res16", "fp8", "fp8-res16", "fp8-mlp"],
-                    help="bf16 operands with a bf16 (default, the product's default) or fp32 residual stream; fp8 variants")
+                    help="bf16 operands with an fp32 (default, the product's default) or bf16 residual stream; fp8 variants")
     ap.add_argument("--image-slice", type=int, default=0, help="experiment: images per encoder launch (default: the engine's 255)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="A/B only: force a GEMM tile variant (0 = the library's choice)")
     ap.add_argument("--text-group", type=int, default=0, help="texts per encoder call (0 = engine.tile_friendly_batch: 851 for ViT-L/14; 255 = one call per text column and step, round 1 / early round 2)")
@@ -170,9 +172,9 @@ def main():
     if args.gemm_variant:
         engine.set_gemm_variant(args.gemm_variant)
     if args.resadd >= 0:
-        engine.set_gemm_variant((args.resadd + 1) << 28)
-    # residual add inside the out-proj / fc2 epilogues: the library's default for bf16 residual streams (KEMR_RESADD=0 turns it off)
-    resadd_on = args.precision.endswith("res16") and bool(args.resadd if args.resadd >= 0 else int(os.environ.get("KEMR_RESADD", "1") or "1"))
+        eng.set_residual_fusion(bool(args.resadd))
+    # residual add inside the out-proj / fc2 epilogues: the library's default (KEMR_RESADD=0 turns it off)
+    resadd_on = eng.residual_fusion()
     eng.load_state_dict(random_weights(arch, seed=0))
 
     g = torch.Generator().manual_seed(1234 + rank)
@@ -191,7 +193,7 @@ def main():
 
     class Stepper:
         def __init__(self, e, resadd):
-            self.resadd = bool(resadd)
+            self.resadd = (2 if e.precision.endswith("res16") else 4) if resadd else 0      # bytes per in-place C element, census
             self.e, self.pending, self.images, self.texts, self.calls = e, 0, 0, 0, all_calls      # pooled texts; items encoded so far; the process-wide call list
 
         def step(self):
@@ -295,7 +297,7 @@ def main():
     # attached only to the configuration it was measured for.
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-    if os.path.exists(tpath) and args.model == "ViT-L/14" and B == 255 and args.precision == "bf16-res16" and resadd_on and args.gemm_variant == 0 and not args.text_group:
+    if os.path.exists(tpath) and args.model == "ViT-L/14" and B == 255 and args.precision == json.load(open(tpath)).get("precision", "bf16-res16") and resadd_on and args.gemm_variant == 0 and not args.text_group:
         with open(tpath) as f:
             tj = json.load(f)
         traffic, traffic_source = tj.get("bytes_per_launch"), {k: tj.get(k) for k in ("profile", "round", "commit", "algorithmic_bytes_per_launch")}
@@ -386,11 +388,11 @@ def main():
     # ------------------------------------------------------------------ sub-results: the same step at other precisions
     if not args.no_extras and args.precision == _lib.DEFAULT_PRECISION:
         extras = {}
-        for prec in ("bf16", "fp8", "fp8-res16"):
+        for prec in ("bf16-res16", "fp8", "fp8-res16"):
             e2 = engine.ClipEngine(arch, dev, precision=prec)
             e2.load_state_dict(random_weights(arch, seed=0))
 
-            s2 = Stepper(e2, resadd_on and prec.endswith("res16"))
+            s2 = Stepper(e2, e2.residual_fusion())
             for _ in range(3):
                 s2.step()
             s2.drain()
@@ -415,7 +417,7 @@ def main():
         if resadd_on:
             # the same engine with the store-only epilogues (updates applied by the LayerNorms): the GEMM class then holds GEMM
             # work only, which is the configuration the GEMM's own roofline fraction is best read on
-            engine.set_residual_fusion(False)
+            eng.set_residual_fusion(False)
             s3 = Stepper(eng, False)
             for _ in range(3):
                 s3.step()
@@ -428,7 +430,7 @@ def main():
             barrier()
             dt = time.perf_counter() - t1
             ms3, n3, fl3 = profile_region(s3)
-            engine.set_residual_fusion(True)
+            eng.set_residual_fusion(True)
             a3 = fl3 / (ms3[0] * 1e-3) / 1e12
             result["roofline_store_only_epilogues"] = {
                 "config": "KEMR_RESADD=0: out-proj / fc2 store deltas, the LayerNorms apply them (round 2's earlier default)",

@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define KEMR_ABI_VERSION 1
+/* 2: kemr_sim_workspace_bytes takes kdim, panels are allocated with ceil256(rows) rows (kemr_panel_build zero-fills up to
+ *    256), kemr_model_set_option / kemr_model_get_option, the tools' switches live in kemr_debug.h (kemr_debug_set). */
+#define KEMR_ABI_VERSION 2
 
 typedef enum kemr_status {
     KEMR_OK = 0,
@@ -44,7 +46,9 @@ typedef enum kemr_status {
 typedef enum kemr_dtype { KEMR_F32 = 0, KEMR_BF16 = 1, KEMR_I32 = 2, KEMR_FP8 = 3 /* OCP e4m3fn */ } kemr_dtype;
 
 /* compute precision of the encoder GEMMs (activations + weights); accumulation is always fp32 */
-/* KEMR_PREC_BF16:       bf16 GEMM / attention operands, fp32 residual stream (closest to the reference's .float() model)
+/* KEMR_PREC_BF16:       the default.  bf16 GEMM / attention operands, fp32 accumulation, fp32 residual stream (closest to the
+ *                       reference's .float() model); the out-proj / fc2 updates are stored as bf16 and added in fp32 by the
+ *                       LayerNorms (option "residual_fusion" = 2 adds them in the GEMM epilogues without rounding them).
  * KEMR_PREC_BF16_RES16: as above with the residual stream stored as bf16 between layers (what fp16/bf16 CLIP inference
  *                       does everywhere); LayerNorm statistics and the residual add stay fp32.  8 instead of 12 bytes
  *                       of HBM traffic per residual element and LayerNorm, and 16 instead of 18 workspace bytes.
@@ -96,6 +100,13 @@ int kemr_model_load_tensor(kemr_model* m, const char* name, const void* host_ptr
                            const int64_t* shape, int rank);
 int kemr_model_finalize(kemr_model* m, int precision /*kemr_precision*/);
 int kemr_model_destroy(kemr_model* m);
+/* Per-model options (any time after create; take effect on the next encode call of this model, no other model is touched):
+ *   "residual_fusion"  calls of more than 512 token rows add the residual inside the out-proj / fc2 GEMM epilogues instead of
+ *                      storing bf16 updates that the LayerNorms apply: 0 never; 1 (default; KEMR_RESADD in the environment at
+ *                      create overrides) for bf16 residual streams (x is then rounded twice per layer instead of once); 2 for
+ *                      fp32 residual streams as well (x += A.W^T + b in fp32, no update is rounded at all; slower). */
+int kemr_model_set_option(kemr_model* m, const char* key, int value);
+int kemr_model_get_option(const kemr_model* m, const char* key, int* value);
 /* number of required tensor names; name i via kemr_model_tensor_name (for strict-load diagnostics) */
 int kemr_model_num_tensors(const kemr_model* m);
 const char* kemr_model_tensor_name(const kemr_model* m, int i);
@@ -159,11 +170,6 @@ int kemr_panel_build(const float* const* parts_dev, const float* part_scale, con
  *   order rule, same outputs bit for bit; lists that overflow re-run the slower kernel on the device (no host round trip).
  *   workspace >= kemr_sim_workspace_bytes(nq, ng, kdim, k), 256-byte aligned */
 size_t kemr_sim_workspace_bytes(int nq, int ng, int64_t kdim, int k);
-/* tools / tests: 0 = never the candidate-list path, 1 = where it applies (default), 2 = lists, then the fallback forced */
-int kemr_set_sim_lists(int mode);
-/* tools: flag / longest list / capacity / chunks / sampled rows / records per query left in `workspace` by the last
- * kemr_sim_topk of these sizes on the candidate-list route (all zero when the route does not apply; synchronises) */
-int kemr_debug_sim_lists(const void* workspace_dev, int nq, int ng, int64_t kdim, int k, int32_t* out6);
 int kemr_sim_topk(const void* q_panel_dev, int nq, const void* g_panel_dev, int ng, int64_t kdim,
                   int64_t gallery_offset, int k, float* top_scores_dev, int32_t* top_idx_dev,
                   const int32_t* gt_idx_dev, const float* gt_score_dev, int32_t* ahead_dev,
@@ -221,7 +227,8 @@ int kemr_profile_end(double* ms_per_class, int64_t* launches_per_class, int ncla
 typedef enum kemr_epilogue {
     KEMR_EPI_BIAS_BF16 = 0,        /* C_bf16 = A.W^T + bias                                  */
     KEMR_EPI_BIAS_QGELU_BF16 = 1,  /* C_bf16 = quickgelu(A.W^T + bias)                       */
-    KEMR_EPI_BIAS_RESID_F32 = 2,   /* X_f32 += A.W^T + bias   (in place on the residual)      */
+    KEMR_EPI_BIAS_RESID_F32 = 2,   /* X_f32 += A.W^T + bias   (in place on the residual; from 128 output tiles of 256 x 256 and more
+                                      than 512 rows up the persistent kernel: C with ceil256(m) rows) */
     KEMR_EPI_BIAS_RESADD_BF16 = 4  /* X_bf16 = bf16(bf16(A.W^T + bias) + X_bf16), in place; persistent 256 x 256 kernel only:
                                       N % 256 == 0, m > 512, C with ceil256(m) rows                              */
 } kemr_epilogue;
@@ -243,15 +250,6 @@ int kemr_preprocess_u8_batch(const unsigned char* packed_dev, const int64_t* off
                              const int32_t* widths, int batch, int n_px, float* out_dev, void* workspace_dev,
                              size_t workspace_bytes, void* stream);
 
-/* tile variant used by every GEMM launch: 0 = automatic (default: 7 for the bf16 epilogues from 128 tiles up), 1 = 128x128x64
- * / 4 waves, 2 = 256x256x64 / 8 waves in lockstep, 3 = the same with staggered wave halves, 4 / 5 = persistent 256x256 with a
- * per-tile prologue (4 / 2 phases per K-tile), 6 = persistent, 4 waves x 128x128 (AGPR accumulators), 7 = persistent 8 waves,
- * one K-tile pipeline across tiles, non-temporal C stores (2-7 need N % 256 == 0; 4-7 the bf16 epilogues), 8 = skinny-M split-K
- * (default up to 512 rows, bf16 epilogues), 9 = persistent, 4 waves x 128x128, register-staged operands; A/B and tests */
-int kemr_set_gemm_variant(int variant);
-/* tools/ only: cycle sums the persistent GEMM's diagnostic instantiation left behind (variant flag bit 14): 16 words per
- * workgroup = 8 barrier intervals of the K loop, K-loop tail, epilogue, tiles, K-tiles per tile.  Synchronises the device. */
-int kemr_debug_gemm_stamps(unsigned* host_out, int n_words);
 int kemr_op_gemm(const void* a_dev, const void* w_dev, const float* bias_dev, void* c_dev,
                  int m, int n, int k, int epilogue, void* stream);
 int kemr_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, void* y_dev,

@@ -1,0 +1,44 @@
+/*
+ * kemr_debug.h -- experiment switches and diagnostics of libkemr.so for tools/ and tests/.
+ *
+ * NOT part of the product ABI (include/kemr.h): everything here is process-wide, not thread-safe, and may change a caller's
+ * timing or route -- never its results, which tests/ check on every route.  Per-model behaviour that does change numerics
+ * (the residual fusion) is a model option in kemr.h (kemr_model_set_option), not a switch here.
+ */
+#ifndef KEMR_DEBUG_H_
+#define KEMR_DEBUG_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One key per switch; a call touches that switch only.
+ *   "gemm_variant"  0 = automatic (default), 1 = 128x128x64 / 4 waves, 2 / 3 = 256x256x64 / 8 waves in lockstep / staggered,
+ *                   7 = persistent 8 waves with one K-tile pipeline across tiles (the automatic choice from 128 tiles up),
+ *                   8 = skinny-M split-K (automatic up to 512 rows); 4, 5, 6, 9 = earlier persistent generations, only in a
+ *                   library built with `build.py --ab-variants`
+ *   "gemm_flags"    timing experiments of the persistent GEMM's diagnostic instantiation: 1 = drop the C stores, 4 = plain
+ *                   instead of non-temporal stores, 64 (+ 32) = cycle stamps per barrier interval, 128 = whole-kernel clock
+ *   "gemm_order"    tile order of the persistent GEMM: 0 = N fastest, else log2(column-group width) + 1 (default 3)
+ *   "gemm_conc"     both wave halves' epilogues in one barrier interval: 0 never, 1 always, 2 = QuickGELU epilogue only (default)
+ *   "gemm_kl"       K loop of the persistent GEMM: 0 = eight 256-cycle barrier intervals per K-tile (default), 1 = four of 512
+ *   "attn_waves"    waves per attention workgroup at T = 257: 0 = default (4), 6
+ *   "sim_lists"     kemr_sim_topk: 0 = never the candidate-list route, 1 = where it applies (default), 2 = lists, then the
+ *                   exact fallback forced */
+int kemr_debug_set(const char* key, int value);
+int kemr_debug_get(const char* key, int* value);
+
+/* flag / longest list / capacity / chunks / sampled rows / records per query left in `workspace` by the last kemr_sim_topk of
+ * these sizes on the candidate-list route (all zero when the route does not apply; synchronises the device) */
+int kemr_debug_sim_lists(const void* workspace_dev, int nq, int ng, int64_t kdim, int k, int32_t* out6);
+
+/* cycle sums the persistent GEMM's diagnostic instantiation left behind ("gemm_flags" 64): 16 words per workgroup = the barrier
+ * intervals of the K loop, K-loop tail, epilogue, tiles, K-tiles per tile.  Synchronises the device. */
+int kemr_debug_gemm_stamps(unsigned* host_out, int n_words);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KEMR_DEBUG_H_ */

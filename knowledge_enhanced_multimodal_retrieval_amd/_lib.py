@@ -21,9 +21,11 @@ PREC_BF16_RES16 = 2
 PREC_FP8 = 3
 PREC_FP8_MLP = 4
 PREC_FP8_RES16 = 5
-# default of the product: bf16 GEMM / attention operands AND a bf16 residual stream (LayerNorm statistics and the residual add stay
-# fp32): at the bench shape 1 - cos against the fp32 oracle is 4e-5 (bar 1e-3) for +3.7 % throughput; "bf16" keeps the stream fp32
-DEFAULT_PRECISION = "bf16-res16"
+# default of the product: bf16 GEMM / attention operands, fp32 accumulation and an fp32 residual stream that the out-proj / fc2
+# GEMMs add into in their epilogues (no update is ever rounded): the mode that meets north_star's bars (1 - cos against the fp32
+# oracle 3e-6 at the bench shape; Recall@10 of the stress test inside the fixed 0.2-point bar).  "bf16-res16" stores the stream as
+# bf16 (+ ~4 % items/s, 1 - cos 8e-5, Recall@10 drifts 0.5 points on that test): opt-in through KEMR_PRECISION, never the default.
+DEFAULT_PRECISION = "bf16"
 PRECISIONS = {"bf16": PREC_BF16, "bf16-res16": PREC_BF16_RES16, "fp8": PREC_FP8, "fp8-mlp": PREC_FP8_MLP, "fp8-res16": PREC_FP8_RES16}
 TOWER_VISION, TOWER_TEXT = 0, 1
 SIDE_QUERY, SIDE_GALLERY = 0, 1
@@ -46,6 +48,8 @@ SIGNATURES = {
     "kemr_model_load_tensor": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(_i64), _i]),
     "kemr_model_finalize": (_i, [_vp, _i]),
     "kemr_model_destroy": (_i, [_vp]),
+    "kemr_model_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "kemr_model_get_option": (_i, [_vp, C.c_char_p, C.POINTER(_i)]),
     "kemr_model_num_tensors": (_i, [_vp]),
     "kemr_model_tensor_name": (C.c_char_p, [_vp, _i]),
     "kemr_workspace_bytes": (_sz, [_vp, _i, _i]),
@@ -54,8 +58,6 @@ SIGNATURES = {
     "kemr_panel_kdim": (_i64, [_i, _i, _i]),
     "kemr_panel_build": (_i, [C.POINTER(_vp), C.POINTER(_f), C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp]),
     "kemr_sim_workspace_bytes": (_sz, [_i, _i, _i64, _i]),
-    "kemr_set_sim_lists": (_i, [_i]),
-    "kemr_debug_sim_lists": (_i, [_vp, _i, _i, _i64, _i, _vp]),
     "kemr_sim_topk": (_i, [_vp, _i, _vp, _i, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kemr_pair_scores": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _vp, _vp]),
     "kemr_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
@@ -65,8 +67,6 @@ SIGNATURES = {
     "kemr_cross_attention_pairs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _vp]),
     "kemr_profile_begin": (_i, [_i]),
     "kemr_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i64), _i]),
-    "kemr_set_gemm_variant": (_i, [_i]),
-    "kemr_debug_gemm_stamps": (_i, [_vp, _i]),
     "kemr_op_gemm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "kemr_preprocess_workspace_bytes": (_sz, [_i, _i, _i]),
     "kemr_preprocess_u8": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
@@ -79,6 +79,15 @@ SIGNATURES = {
     "kemr_op_layernorm_rows": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "kemr_op_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
 }
+
+# include/kemr_debug.h: experiment switches and diagnostics for tools/ and tests/ (process-wide; not the product ABI)
+DEBUG_SIGNATURES = {
+    "kemr_debug_set": (_i, [C.c_char_p, _i]),
+    "kemr_debug_get": (_i, [C.c_char_p, C.POINTER(_i)]),
+    "kemr_debug_sim_lists": (_i, [_vp, _i, _i, _i64, _i, _vp]),
+    "kemr_debug_gemm_stamps": (_i, [_vp, _i]),
+}
+ABI_VERSION = 2
 
 _lock = threading.Lock()
 _lib = None
@@ -101,15 +110,15 @@ def lib() -> C.CDLL:
         # process ends up with two HIP runtimes and every HIP call of libkemr fails with hipErrorNoDevice.
         import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
             try:
                 fn = getattr(handle, name)
             except AttributeError as e:
                 raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
             fn.restype = res
             fn.argtypes = args
-        if handle.kemr_abi_version() != 1:
-            raise RuntimeError("libkemr.so ABI version mismatch; rebuild the library")
+        if handle.kemr_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libkemr.so ABI version {handle.kemr_abi_version()} != {ABI_VERSION}; rebuild the library")
         _lib = handle
         return _lib
 

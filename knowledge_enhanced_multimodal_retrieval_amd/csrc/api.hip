@@ -1,6 +1,7 @@
 // libkemr.so: model handle, weight packing and the encoder launch sequences behind the C ABI (include/kemr.h).
 // Host-side C++ only; every kernel lives in gemm.hip / layernorm.hip / attention.hip / embed.hip / sim.hip.
 #include "common.h"
+#include "../../include/kemr_debug.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -72,6 +73,7 @@ struct kemr_model {
     int grid = 0, patches = 0, kpad = 0;
     int res_dtype = KEMR_F32;                       // storage type of the residual stream (KEMR_PREC_BF16_RES16: bf16)
     int fp8 = 0;                                    // bit 0: QKV on fp8 operands (KEMR_PREC_FP8), bit 1: fc1 too (KEMR_PREC_FP8_MLP)
+    int resadd = 1;                                 // option "residual_fusion": residual add inside the out-proj / fc2 epilogues
     // vision
     TowerW vis;
     const bf16_t* conv_w = nullptr;
@@ -133,6 +135,7 @@ extern "C" int kemr_model_create(const kemr_cfg* cfg, kemr_model** out) {
     kemr_model* m = new (std::nothrow) kemr_model();
     if (!m) KEMR_FAIL(KEMR_ERR_NOMEM, "model_create: out of memory");
     m->cfg = *cfg;
+    { const char* v = getenv("KEMR_RESADD"); const int e = (v && *v) ? atoi(v) : 1; m->resadd = e < 0 ? 0 : e > 2 ? 2 : e; }
     m->grid = cfg->image_size / cfg->patch;
     m->patches = m->grid * m->grid;
     m->kpad = (int)round_up(3 * cfg->patch * cfg->patch, 64);
@@ -348,19 +351,28 @@ int carve(Workspace& w, void* base, size_t bytes, int width, int tokens, int bat
 // ln_2 normalises x + delta without writing x; the next block's ln_1 writes x += delta + delta2 once and normalises it.
 // On return both deltas of the last block are still pending; the caller's tail adds them.
 //
-// g_resadd (bf16 residual stream, calls the persistent GEMM takes whole): the out-proj and fc2 epilogues read the x tile they
-// overwrite and add it (EPI_BIAS_RESADD_BF16), both LayerNorms read x and write h only: 8 instead of 16 bytes per element and
-// layer in the LayerNorms against 28 kB more per output tile in those two GEMMs.  x is then rounded to bf16 twice per
-// layer (after the attention update and after the MLP update) instead of once.  *pending = deltas left for the tail.
-int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, int fp8, hipStream_t s, bool* pending) {
+// Option "residual_fusion" (calls of more than 512 token rows that the persistent GEMM takes whole): the out-proj and fc2
+// epilogues read the x tile they overwrite and add it, both LayerNorms read x and write h only.
+//  * bf16 residual stream (value >= 1, the default): EPI_BIAS_RESADD_BF16, 8 instead of 16 bytes per element and layer in the
+//    LayerNorms; x is then rounded to bf16 twice per layer (after the attention update and after the MLP update) instead of once.
+//  * fp32 residual stream (value 2 only): EPI_BIAS_RESID_F32, x += A.W^T + bias in fp32 in the accumulator domain -- no delta
+//    buffers, no rounding of the updates at all (the store-only form rounds each update to bf16), 12 instead of 22 bytes per
+//    element and layer in the LayerNorms.  NOT the default: measured (round 3, ViT-L/14 at B = 255, same device) the two GEMMs pay
+//    +77 us (out-proj, 106 -> 183) and +62 us (fc2, 402 -> 464) per layer for 112 us of LayerNorm time saved -- every workgroup of
+//    the persistent kernel reaches its tile boundary at the same moment, so the 0.54 GB an epilogue round moves arrive as a burst
+//    at the HBM roofline with the matrix cores idle, and out-proj with 0.67 GB per launch is HBM-bound outright (122 us at best).
+// *pending = deltas left for the tail.
+int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, int fp8, int want_resadd, hipStream_t s, bool* pending) {
     const int W = t.width, M = batch * t.tokens;
     const bool fq = fp8 & 1, f1 = fp8 & 2;          // LayerNorm output = A operand of QKV / fc1: e4m3 where that GEMM runs in fp8
-    bool resadd = g_resadd && w.x_dtype == KEMR_BF16 && M > 512 && W % 256 == 0;
+    bool resadd = want_resadd >= (w.x_dtype == KEMR_BF16 ? 1 : 2) && M > 512 && W % 256 == 0;
+    const int cs = w.x_dtype == KEMR_BF16 ? 2 : 4;
+    const int epi_res = w.x_dtype == KEMR_BF16 ? EPI_BIAS_RESADD_BF16 : EPI_BIAS_RESID_F32;
     if (resadd) {
         GemmParams a{}, b{};
         a.M = b.M = M; a.N = b.N = W; a.K = W; b.K = 4 * W; a.lda = W; b.lda = 4 * W; a.ldw = W; b.ldw = 4 * W; a.ldc = b.ldc = W;
         a.c_rows_padded = b.c_rows_padded = 1;
-        resadd = gemm256u_fits(a, 2) && gemm256u_fits(b, 2);
+        resadd = gemm256u_fits(a, 2, cs) && gemm256u_fits(b, 2, cs);
     }
     *pending = !resadd && t.layers > 0;
     for (int l = 0; l < t.layers; ++l) {
@@ -380,7 +392,7 @@ int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, int f
         }
         KEMR_TRY(launch_attention(w.big, w.h, batch, t.tokens, W, causal, s));
         g.A = w.h; g.lda = W; g.W = L.wo; g.ldw = W; g.bias = L.bo; g.C = resadd ? w.x : (void*)w.delta; g.ldc = W; g.N = W; g.K = W;
-        KEMR_TRY(launch_gemm(g, resadd ? EPI_BIAS_RESADD_BF16 : EPI_BIAS_BF16, s));
+        KEMR_TRY(launch_gemm(g, resadd ? epi_res : EPI_BIAS_BF16, s));
         KEMR_TRY(launch_layernorm(w.x, w.x_dtype, resadd ? nullptr : w.delta, nullptr, 0, L.ln2_g, L.ln2_b, w.h, M, W, f1 ? KEMR_FP8 : KEMR_BF16, s));
         g.A = w.h; g.lda = W; g.W = L.w1; g.ldw = W; g.bias = L.b1; g.C = w.big; g.ldc = 4 * W; g.N = 4 * W; g.K = W;
         if (f1) {
@@ -391,7 +403,7 @@ int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, int f
             KEMR_TRY(launch_gemm(g, EPI_BIAS_QGELU_BF16, s));
         }
         g.A = w.big; g.lda = 4 * W; g.W = L.w2; g.ldw = 4 * W; g.bias = L.b2; g.C = resadd ? w.x : (void*)w.delta2; g.ldc = W; g.N = W; g.K = 4 * W;
-        KEMR_TRY(launch_gemm(g, resadd ? EPI_BIAS_RESADD_BF16 : EPI_BIAS_BF16, s));
+        KEMR_TRY(launch_gemm(g, resadd ? epi_res : EPI_BIAS_BF16, s));
     }
     return KEMR_OK;
 }
@@ -423,7 +435,7 @@ extern "C" int kemr_encode_image(kemr_model* m, const float* pixels_dev, int bat
     KEMR_TRY(launch_cls_rows(w.x32, m->cls, m->vpos, batch, T, W, s));
     KEMR_TRY(launch_layernorm(w.x32, KEMR_F32, nullptr, nullptr, 0, m->lnpre_g, m->lnpre_b, w.x, batch * T, W, w.x_dtype, s));
     bool vb = false;
-    KEMR_TRY(run_blocks(m->vis, w, batch, 0, m->fp8, s, &vb));
+    KEMR_TRY(run_blocks(m->vis, w, batch, 0, m->fp8, m->resadd, s, &vb));
     KEMR_TRY(launch_tail(w.x, w.x_dtype, vb ? w.delta : nullptr, vb ? w.delta2 : nullptr, nullptr, batch, T, W, m->lnpost_g, m->lnpost_b, m->vproj, m->cfg.embed_dim, normalize, out_dev, s));
     return KEMR_OK;
 }
@@ -440,21 +452,70 @@ extern "C" int kemr_encode_text(kemr_model* m, const int32_t* ids_dev, int batch
     KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, T, batch, m->res_dtype));
     KEMR_TRY(launch_text_embed(ids_dev, m->tok, m->tpos, w.x, w.x_dtype, batch, T, W, m->cfg.vocab, s));
     bool tb = false;
-    KEMR_TRY(run_blocks(m->txt, w, batch, 1, m->fp8, s, &tb));
+    KEMR_TRY(run_blocks(m->txt, w, batch, 1, m->fp8, m->resadd, s, &tb));
     KEMR_TRY(launch_tail(w.x, w.x_dtype, tb ? w.delta : nullptr, tb ? w.delta2 : nullptr, ids_dev, batch, T, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s));
     return KEMR_OK;
 }
 
-extern "C" int kemr_set_gemm_variant(int variant) {
-    g_gemm_dbg = (variant >> 8) & 0xff;   // bits 8..15: timing-experiment flags (tools/ only)
-    if ((variant >> 16) & 0xf) g_gemm_order = ((variant >> 16) & 0xf) - 1;
-    if ((variant >> 24) & 0xf) g_attn_waves = ((variant >> 24) & 0xf) - 1;   // bits 24..27: attention waves per workgroup for T = 257 (+ 1; 0 / 4 default, 6) (tools/ only)
-    if ((variant >> 28) & 0x3) g_resadd = ((variant >> 28) & 0x3) - 1;       // bits 28..29: residual add in the out-proj / fc2 epilogues (+ 1) (tools / tests)
-    if ((variant >> 20) & 0x3) g_gemm_conc = ((variant >> 20) & 0x3) - 1;     // bits 20..21: gemm256u concurrent epilogues (0 never / 1 always / 2 QuickGELU only) + 1 (tools/ only; 0 keeps the current setting)   // bits 16..19: gemm256u tile order + 1 (tools/ only; 0 keeps the current one)
-    variant &= 0xff;
-    if (variant < 0 || variant > 9) KEMR_FAIL(KEMR_ERR_INVALID, "set_gemm_variant: 0 auto, 1 = 128x128, 2 = 256x256 lockstep, 3 = 256x256 staggered, 4 / 5 = persistent 8-wave (4 / 2 phases per K-tile), 6 = persistent 4-wave, 7 = persistent 8-wave with one K-tile pipeline across tiles, 8 = skinny-M split-K, 9 = persistent 4-wave with register-staged operands");
-    g_gemm_variant = variant & 0xff;
-    return KEMR_OK;
+// ------------------------------------------------------------------------------------------------ per-model options
+extern "C" int kemr_model_set_option(kemr_model* m, const char* key, int value) {
+    if (!m || !key) KEMR_FAIL(KEMR_ERR_INVALID, "model_set_option: null argument");
+    if (!strcmp(key, "residual_fusion")) {
+        if (value < 0 || value > 2) KEMR_FAIL(KEMR_ERR_INVALID, "model_set_option(residual_fusion): 0, 1 or 2, got %d", value);
+        m->resadd = value;
+        return KEMR_OK;
+    }
+    KEMR_FAIL(KEMR_ERR_INVALID, "model_set_option: unknown key '%s'", key);
+}
+
+extern "C" int kemr_model_get_option(const kemr_model* m, const char* key, int* value) {
+    if (!m || !key || !value) KEMR_FAIL(KEMR_ERR_INVALID, "model_get_option: null argument");
+    if (!strcmp(key, "residual_fusion")) { *value = m->resadd; return KEMR_OK; }
+    if (!strcmp(key, "precision_residual_bf16")) { *value = m->res_dtype == KEMR_BF16; return KEMR_OK; }
+    KEMR_FAIL(KEMR_ERR_INVALID, "model_get_option: unknown key '%s'", key);
+}
+
+// ------------------------------------------------------------------------------------------------ include/kemr_debug.h
+// Process-wide experiment switches of tools/ and tests/ (not thread-safe, not part of the product ABI): one key per knob.
+namespace {
+struct DebugKnob { const char* key; int* var; int lo, hi; };
+int* sim_lists_knob();
+const DebugKnob* debug_knobs(int* n) {
+    static const DebugKnob knobs[] = {
+        {"gemm_variant", &g_gemm_variant, 0, 9},      // 0 auto, 1 = 128x128, 2 / 3 = 256x256 lockstep / staggered, 4-6, 9 = A/B generations (build.py --ab-variants), 7 = persistent, 8 = skinny
+        {"gemm_flags", &g_gemm_dbg, 0, 255},          // timing-experiment flags of the DBG instantiation (1 drop stores, 4 plain stores, 32 / 64 / 128 stamps)
+        {"gemm_order", &g_gemm_order, 0, 8},          // gemm256u tile order (0 = N fastest, else log2(column-group width) + 1)
+        {"gemm_conc", &g_gemm_conc, 0, 2},            // both wave halves' epilogues in one barrier interval: 0 never, 1 always, 2 = QuickGELU only
+        {"gemm_kl", &g_gemm_kl, 0, 1},                // 0 = eight 256-cycle barrier intervals per K-tile (default), 1 = four of 512 (round-3 experiment)
+        {"attn_waves", &g_attn_waves, 0, 6},          // waves per attention workgroup at T = 257 (0 = default)
+        {"sim_lists", sim_lists_knob(), 0, 2},        // 0 = never the candidate-list route, 1 = where it applies, 2 = lists, then the fallback forced
+    };
+    *n = (int)(sizeof(knobs) / sizeof(knobs[0]));
+    return knobs;
+}
+int* sim_lists_knob() { return &g_sim_lists; }
+}  // namespace
+
+extern "C" int kemr_debug_set(const char* key, int value) {
+    if (!key) KEMR_FAIL(KEMR_ERR_INVALID, "debug_set: null key");
+    int n = 0;
+    const DebugKnob* k = debug_knobs(&n);
+    for (int i = 0; i < n; ++i)
+        if (!strcmp(k[i].key, key)) {
+            if (value < k[i].lo || value > k[i].hi) KEMR_FAIL(KEMR_ERR_INVALID, "debug_set(%s): %d not in %d..%d", key, value, k[i].lo, k[i].hi);
+            *k[i].var = value;
+            return KEMR_OK;
+        }
+    KEMR_FAIL(KEMR_ERR_INVALID, "debug_set: unknown key '%s'", key);
+}
+
+extern "C" int kemr_debug_get(const char* key, int* value) {
+    if (!key || !value) KEMR_FAIL(KEMR_ERR_INVALID, "debug_get: null argument");
+    int n = 0;
+    const DebugKnob* k = debug_knobs(&n);
+    for (int i = 0; i < n; ++i)
+        if (!strcmp(k[i].key, key)) { *value = *k[i].var; return KEMR_OK; }
+    KEMR_FAIL(KEMR_ERR_INVALID, "debug_get: unknown key '%s'", key);
 }
 
 extern "C" int kemr_debug_gemm_stamps(unsigned* host_out, int n_words) {

@@ -141,8 +141,9 @@ struct GemmParams {
 };
 extern int g_gemm_dbg;
 extern int g_gemm_order;
-extern int g_resadd;        // api.hip: residual add inside the out-proj / fc2 epilogues for bf16 residual streams
+extern int g_sim_lists;     // sim.hip: candidate-list route of kemr_sim_topk (kemr_debug_set "sim_lists")
 extern int g_attn_waves;    // attention.hip (tools)
+extern int g_gemm_kl;       // gemm256u: 1 = long-interval K loop (round 3, default), 0 = round 2's (tools/ A/B)
 extern int g_gemm_conc;     // gemm256u: both wave halves run their epilogues in the same barrier interval (0 never, 1 always, 2 = QuickGELU epilogue only)
 int gemm_read_stamps(unsigned* host_out, int n_words);
 int launch_gemm256u_simgmax(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, float* out, hipStream_t stream,
@@ -157,7 +158,7 @@ int launch_gemm256(const GemmParams& p, int epi, hipStream_t stream);   // gemm2
 int launch_gemm256p(const GemmParams& p, int epi, hipStream_t stream);  // gemm256p.hip: persistent, async epilogue (bf16-store epilogues)
 int launch_gemm256q(const GemmParams& p, int epi, hipStream_t stream);  // gemm256q.hip: persistent, 2 long phases per K-tile
 int launch_gemm256u(const GemmParams& p, int epi, hipStream_t stream);  // gemm256u.hip: gemm256p's K loop, one K-tile pipeline across tiles
-bool gemm256u_fits(const GemmParams& p, int elem_size);
+bool gemm256u_fits(const GemmParams& p, int elem_size, int c_elem_size = 2);
 // rank-only similarity pass on the persistent GEMM's K loop (k == 0, no bonus); false in *used when the shape does not fit it
 int launch_gemm256u_simrank(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, long long gallery_offset,
                             const int32_t* gt_idx, const float* gt_score, int32_t* ahead, hipStream_t stream, bool* used);               // gemm256u.hip: inside its tile table / 32-bit offsets

@@ -171,14 +171,11 @@ int g_gemm_variant = 0;
 int g_gemm_dbg = 0;
 int g_gemm_order = 3;
 int g_gemm_conc = 2;
-// Residual add inside the out-proj / fc2 epilogues for bf16 residual streams (api.hip run_blocks): on unless KEMR_RESADD=0
-// (measured, round 2, same device: 16 690 -> 17 300 items/s, LayerNorm 5.25 -> 2.75 ms, GEMMs 34.9 -> 35.9 ms per step;
-// image 1 - cos against the fp32 oracle 4.2e-5 -> 8.0e-5: x is rounded twice per layer instead of once)
-static int env_flag(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) != 0 : dflt;
-}
-int g_resadd = env_flag("KEMR_RESADD", 1);      // gemm256u tile order: column groups of 4 tiles (tools/bench_gemm_r2.py: fc1 -1 %, QKV -0.4 % against N fastest)
+// gemm256u K loop: 0 = eight 256-cycle barrier intervals per K-tile (round 2; the default), 1 = four of 512 (round 3 experiment:
+// half the hand-overs, but the W pieces of a K-tile then have ONE interval of flight before the wait that needs them -- their
+// region is read until two intervals before -- and the stall eats the gain: 402 -> 414 us on fc2, 106 -> 111 on out-proj, same
+// device, bit-identical results; tools/bench_gemm_r3.py)
+int g_gemm_kl = 0;
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     if (p.M <= 0) return KEMR_OK;
@@ -195,6 +192,11 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
             KEMR_FAIL(KEMR_ERR_INVALID, "gemm: the residual-add epilogue needs N %% 256 == 0, more than 512 rows and a row-padded C (M=%d N=%d K=%d)", p.M, p.N, p.K);
         return launch_gemm256u(p, epi, stream);
     }
+    // fp32 residual stream updated in place: the persistent kernel where it has whole rounds of work (the towers' out-proj / fc2
+    // at more than 512 rows), the earlier kernels below otherwise (same arithmetic up to the position of the bias in the sum)
+    if (epi == EPI_BIAS_RESID_F32 && can256 && p.c_rows_padded && p.M > 512 && (g_gemm_variant == 0 || g_gemm_variant == 7) &&
+        (g_gemm_variant == 7 || tiles256 >= 128) && gemm256u_fits(p, 2, 4))
+        return launch_gemm256u(p, epi, stream);
     // a handful of rows (one or a few online queries): 6-24 tiles would leave the chip idle; split K inside the workgroup
     if (bf16_epi && p.c_rows_padded && (g_gemm_variant == 8 || (g_gemm_variant == 0 && p.M <= 512))) return launch_gemm_skinny(p, epi, stream);
 #ifdef KEMR_AB_VARIANTS      // earlier persistent generations, A/B timing from tools/ only (build.py --ab-variants)

@@ -108,6 +108,36 @@ __device__ __forceinline__ void cluster(f32x4 (&acc)[8][4], const bf16x8 (&af)[4
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+// 32 MFMAs: all 128 rows of the wave's tile x its 64 columns x one 32-wide k step (the long-interval K loop, KL): row tile
+// mi's four MFMAs are issued together, so that af[mi] is dead behind the fourth and the hook of that gap may re-read it IN PLACE
+// for the next cluster (the read's data returns >= 64 cycles later, the MFMA reads its operands in its first passes).
+// ENDWAIT: what the wave waits for behind the cluster's last MFMA, in front of the barrier.
+template <bool FIRST, class Hook>
+__device__ __forceinline__ void cluster32(f32x4 (&acc)[8][4], const bf16x8 (&af)[8], const bf16x8 (&wf)[4], const u32x4 (&b4)[4],
+                                          Hook&& hook) {
+    __builtin_amdgcn_s_setprio(1);
+    asm volatile("s_nop 1" ::: "memory");      // any compiler VALU write just above -> first asm MFMA operand read
+    auto step = [&](auto mi_c, auto ni_c) {
+        constexpr int mi = decltype(mi_c)::value, ni = decltype(ni_c)::value;
+        if constexpr (FIRST)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3"
+                         : "=&v"(acc[mi][ni]) : "v"(wf[ni]), "v"(af[mi]), "v"(b4[ni]));
+        else
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                         : "+v"(acc[mi][ni]) : "v"(wf[ni]), "v"(af[mi]));
+        hook(HookAt<mi * 4 + ni>{});
+    };
+    auto row = [&](auto mi_c) {
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        step(mi_c, I0{}); step(mi_c, I1{}); step(mi_c, I2{}); step(mi_c, I3{});
+    };
+    row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{}); row(std::integral_constant<int, 2>{});
+    row(std::integral_constant<int, 3>{}); row(std::integral_constant<int, 4>{}); row(std::integral_constant<int, 5>{});
+    row(std::integral_constant<int, 6>{}); row(std::integral_constant<int, 7>{});
+    __builtin_amdgcn_s_setprio(0);
+}
+
 // fp8 (OCP e4m3) operands: one block-scaled MFMA covers K = 128 (a lane holds 32 consecutive k bytes of its row), at twice
 // the bf16 MFMA's cycles, i.e. twice the FLOP rate; the E8M0 block scales are all 2^0 (0x7f), the real scales (one per
 // output channel of W) are applied in the epilogue.  A K-tile is still 128 bytes per row: staging, LDS image and swizzle
@@ -147,9 +177,28 @@ constexpr int GEMM256U_MAX_TILES_PER_WG = 62;         // the tile table is one l
 // ahead of the query's ground truth (reference metrics.py:13-76: Recall@K / MRR need nothing else).  One workgroup = one
 // 256-query tile x one chunk of gallery tiles (blockIdx = q_tile * nchunks + chunk); same MFMA operand roles and k order as
 // sim_kernel / pair_scores_kernel (sim.hip), so the scores are theirs bit for bit.
-template <int EPI, bool FP8, bool DBG = false, int SIM = 0, bool CONC = false>
+template <int EPI, bool FP8, bool DBG = false, int SIM = 0, bool CONC = false, bool KL = false>
 __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmParams p) {
     constexpr int ES = FP8 ? 1 : 2;          // operand element size
+    constexpr int CS = EPI == EPI_BIAS_RESID_F32 ? 4 : 2;      // C element size (the fp32 residual stream, else bf16)
+    // LONGK (round 3 experiment, debug switch gemm_kl = 1; NOT the default): two 32-MFMA clusters per K-tile and wave instead of
+    // four 16-MFMA ones, i.e. four barrier intervals of 512 MFMA cycles per K-tile instead of eight of 256, on the reading of round
+    // 2's stamps (an interval takes 300-320 cycles for 256 of MFMA issue) that 50-60 cycles go to the hand-over whatever the
+    // interval's length.  Measured (tools/bench_gemm_r3.py, same device, bit-identical results): 3 % SLOWER on every shape (fc2
+    // 402 -> 414 us, out-proj 106 -> 111, 4096^3 96.4 -> 99.6).  Stamps: the 32-MFMA intervals take 660-740 cycles -- the cost is
+    // per MFMA, not per hand-over (19-20 cycles per MFMA in either loop) -- and the interval that ends with the wait for K-tile
+    // g+1 takes 880: the W regions of a buffer are read until two intervals before they are needed again, so their pieces have
+    // ONE interval of flight here (three in the 8-interval loop).  Schedule per K-tile g (wave half wr = 1 one interval behind):
+    //   LA: stage W(g+1) -> buffer g+1 [+ bias]       MA: acc += . (k 0-31), hooks read W / A (k 32-63) of buffer g, W stream;
+    //                                                     then vmcnt(0): K-tile g+1 has landed (A from LB(g-1), W from LA(g))
+    //   LB: stage A(g+2) -> buffer g (own half)        MB: acc += . (k 32-63), hooks read W / A (k 0-31) of buffer g+1, A stream
+    // Who reads what, when (slots of one interval, half 0: LA 4g, MA 4g+1, LB 4g+2, MB 4g+3; half 1 one later): buffer g is read in
+    // MB(g-1) and MA(g), i.e. slots 4g-1 .. 4g+2.  Its A region (private to a half) is free behind the half's own MA(g): LB(g)
+    // re-stages it.  Its W regions are free from slot 4g+3 on: LA(g+1) (slots 4g+4 / 4g+5) re-stages them with K-tile g+2, which
+    // MB(g+1) (slots 4g+7 / 4g+8) reads behind every wave's vmcnt(0) at the end of its MA(g+1) (slots 4g+5 / 4g+6) and a barrier.
+    // A fragments are re-read in place (cluster32), W fragments alternate between two register sets: 64 VGPRs as before.
+    // Every accumulator still sums k 0-31 before k 32-63 of each K-tile: bit-identical to the round-2 loop.
+    constexpr bool LONGK = KL && !FP8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -220,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     const int t_row_u = __builtin_amdgcn_readfirstlane(t_row);                  // SIM: the workgroup's query tile (the same in every lane)
     const unsigned v_aoff = (unsigned)t_row * (unsigned)(p.lda * ES);          // byte offsets (< 4 GiB: host check)
     const unsigned v_woff = (unsigned)t_col * (unsigned)(p.ldw * ES);
-    const unsigned v_coff = ((unsigned)t_row * (unsigned)p.ldc + (unsigned)t_col) * 2u;
+    const unsigned v_coff = ((unsigned)t_row * (unsigned)p.ldc + (unsigned)t_col) * (unsigned)CS;
     const int v_bcol = t_col;
 
     // staging addresses = wave-uniform K-tile pointer (SGPRs) + a per-lane 32-bit byte offset that never changes
@@ -319,7 +368,8 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             *(int*)(smem + PEPI + 4096 + tid * 4) = 0;
         }
     }
-    // prologue: K-tile 0 complete, both W halves of K-tile 1 in flight (nt >= 2, so all of it belongs to the first tile)
+    // prologue: K-tile 0 complete; in flight behind it (nt >= 2, so all of it belongs to the first tile): both W halves of
+    // K-tile 1, or, LONGK, the wave's A pieces of K-tile 1 (the W stream then stays at K-tile 1, the A stream goes on to 2)
     stage_w(ow, stage_lds + 2 * PHALF);
     stage_w(ow1, stage_lds + 3 * PHALF);
     stage_bias();
@@ -327,15 +377,22 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     stage_a(1, oa, buf_lds);
     advance_w();                               // W stream -> K-tile 1
     advance_a();                               // A stream -> K-tile 1
-    stage_w(ow, stage_lds + PBUF + 2 * PHALF);
-    stage_w(ow1, stage_lds + PBUF + 3 * PHALF);
-    advance_w();                               // W stream -> K-tile 2
+    if constexpr (LONGK) {
+        stage_a(0, oa, buf_lds + PBUF);
+        stage_a(1, oa, buf_lds + PBUF);
+        advance_a();                           // A stream -> K-tile 2
+    } else {
+        stage_w(ow, stage_lds + PBUF + 2 * PHALF);
+        stage_w(ow1, stage_lds + PBUF + 3 * PHALF);
+        advance_w();                           // W stream -> K-tile 2
+    }
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");      // lgkmcnt: the zero-filled bias area (no-bias launches)
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();      // wr == 1 half runs one interval behind for the whole launch
 
     int gpar = 0;
     bf16x8 ak0[4], ak1[4], wk0[4], wk1[4];        // bf16 operands: A rows (current 64-row half) / W columns x k step
+    bf16x8 ak[8];                                  // LONGK: A rows of all 128 rows, one k step, re-read in place
     fp8x32 af8[4], w08[2], w18[2];                 // fp8 operands (only one set is live, by FP8)
     int one = 0x7f7f7f7f;                          // E8M0 block scales 2^0
     asm volatile("" : "+v"(one));
@@ -361,8 +418,13 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     if constexpr (!FP8) {                          // fragments of the first cluster of K-tile 0
 #pragma unroll
         for (int i = 0; i < 4; ++i) { KEMR_DSR(wk0[i], vb0, i * 2048); }
+        if constexpr (LONGK) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { KEMR_DSR(ak0[i], va0, i * 2048); }
+            for (int i = 0; i < 8; ++i) { KEMR_DSR(ak[i], va0, i * 2048); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { KEMR_DSR(ak0[i], va0, i * 2048); }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     // in-kernel stamps (DBG instantiation; wave 0 only): dbg & 64 = cycles per barrier interval of the K loop + epilogue,
@@ -450,6 +512,36 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
         else if constexpr (I >= 10 && I <= 13) step_w(HookAt<I - 9>{});
         else if constexpr (I == 15) { asm volatile("" : "+s"(gpar)); gpar ^= 1; asm volatile("" : "+s"(gpar)); }
     };
+    // LONGK.  MA (k 0-31 of buffer g): reads the k 32-63 fragments of the same buffer -- W into the other register set in the first
+    // gaps, A row tile mi in place in the gap behind its fourth MFMA --, advances the W stream (its offsets were last used in LA)
+    // and then points the k 0-31 bases at the next buffer.  MB (k 32-63): the same with the k 0-31 fragments of buffer g+1, the A
+    // stream (last used in LB) and the k 32-63 bases; gpar flips last.  At most one action per gap.
+    auto hook_la = [&wk1, &ak, &vb0, &vb1, &va0, &va1, &step_w](auto at) {
+        constexpr int I = decltype(at)::value;
+        if constexpr ((I & 3) == 3) { KEMR_DSR(ak[I >> 2], va1, (I >> 2) * 2048); }
+        else if constexpr (I < 3) { KEMR_DSR(wk1[I], vb1, I * 2048); }
+        else if constexpr (I == 4) { KEMR_DSR(wk1[3], vb1, 3 * 2048); }
+        else if constexpr (I == 6) step_w(HookAt<0>{});
+        else if constexpr (I == 9) step_w(HookAt<1>{});
+        else if constexpr (I == 10) step_w(HookAt<2>{});
+        else if constexpr (I == 13) step_w(HookAt<3>{});
+        else if constexpr (I == 14) step_w(HookAt<4>{});
+        else if constexpr (I == 17) { vb0 ^= PBUF; asm volatile("" : "+v"(vb0)); }
+        else if constexpr (I == 18) { va0 ^= PBUF; asm volatile("" : "+v"(va0)); }
+    };
+    auto hook_lb = [&wk0, &ak, &vb0, &vb1, &va0, &va1, &gpar, &step_a](auto at) {
+        constexpr int I = decltype(at)::value;
+        if constexpr ((I & 3) == 3) { KEMR_DSR(ak[I >> 2], va0, (I >> 2) * 2048); }
+        else if constexpr (I < 3) { KEMR_DSR(wk0[I], vb0, I * 2048); }
+        else if constexpr (I == 4) { KEMR_DSR(wk0[3], vb0, 3 * 2048); }
+        else if constexpr (I == 6) step_a(HookAt<0>{});
+        else if constexpr (I == 9) step_a(HookAt<1>{});
+        else if constexpr (I == 10) step_a(HookAt<2>{});
+        else if constexpr (I == 13) step_a(HookAt<3>{});
+        else if constexpr (I == 17) { vb1 ^= PBUF; asm volatile("" : "+v"(vb1)); }
+        else if constexpr (I == 18) { va1 ^= PBUF; asm volatile("" : "+v"(va1)); }
+        else if constexpr (I == 21) { asm volatile("" : "+s"(gpar)); gpar ^= 1; asm volatile("" : "+s"(gpar)); }
+    };
     // fp8: the reads stay in the load intervals; the streams use the same clusters
     auto hook8_m2 = [&step_a](auto at) { constexpr int I = decltype(at)::value; if constexpr (I >= 1 && I <= 9 && (I & 1)) step_a(HookAt<(I - 1) / 2>{}); };
     auto hook8_m4 = [&gpar, &step_w](auto at) {
@@ -502,6 +594,28 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             quad8<1, 0, FIRST>(acc, af8, w08, one, hook8_m4);
             __builtin_amdgcn_s_barrier();
             stamp(7);
+        } else if constexpr (LONGK) {
+            stage_w(ow, stage_lds + (gpar ^ 1) * PBUF + 2 * PHALF);
+            stage_w(ow1, stage_lds + (gpar ^ 1) * PBUF + 3 * PHALF);
+            stage_bias();
+            stamp_pre(10);
+            __builtin_amdgcn_s_barrier();
+            stamp(0);
+            cluster32<FIRST>(acc, ak, wk0, b4, hook_la);
+            // K-tile g+1 has landed: this wave's A pieces from LB(g-1) and W pieces from LA(g) (and everything older: a tile's
+            // stores); the fragment reads of the hooks have returned (orders them in front of LB's re-staging of the A region)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            stamp_pre(11);
+            __builtin_amdgcn_s_barrier();
+            stamp(1);
+            stage_a(0, oa, buf_lds + gpar * PBUF);
+            stage_a(1, oa, buf_lds + gpar * PBUF);
+            __builtin_amdgcn_s_barrier();
+            stamp(2);
+            cluster32<false>(acc, ak, wk1, b4, hook_lb);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stamp(3);
         } else {
             stage_a(0, oa, abuf_next);
             stamp_pre(10);
@@ -685,6 +799,49 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
                 }
             }
             if (wr == 1) __builtin_amdgcn_s_barrier();
+        } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
+            // ---- fp32 residual stream, updated in place in the ACCUMULATOR domain: x += A.W^T + bias (the bias is in the accumulators
+            // since their first MFMA).  A lane's quad acc[mi][ni] is 16 contiguous bytes of row mi*16 + lrow (columns ni*16 + lq*4
+            // .. +3), the 4 lanes of a row make a 64-byte segment and ni = 0 / 1 (2 / 3) the two halves of a 128-byte line: no LDS
+            // transposition, no conversion -- per 16-row pass 4 loads, 16 adds, 4 stores (the bf16 store epilogue: 8 converts, 4 LDS
+            // writes, 2 LDS reads, 2 stores and the LDS round trip; its residual-add form 48 more VALU).  The x quads come in
+            // through a window of two passes; vmcnt retires loads and stores in issue order, so the wait in front of pass p's adds
+            // counts what was issued behind its loads: the next pass's loads and the previous pass's stores.
+            int el = lane;
+            asm volatile("" : "+v"(el));
+            const char* const ctile = (const char*)p.C + __builtin_amdgcn_readlane(v_coff, seq) + ((size_t)(wr * 128) * p.ldc + wc * 64) * 4;     // wave-uniform
+            const unsigned step16 = (unsigned)p.ldc * 64u;                    // 16 rows in bytes
+            unsigned xoff = (unsigned)((el & 15) * p.ldc + (el >> 4) * 4) * 4u, soff = xoff;
+            stamp(8);
+            f32x4 xa[4], xb[4];
+    #define KEMR_XLOAD4(X)                                                                                                          \
+            do {                                                                                                                    \
+                asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:64\n\t"                       \
+                             "global_load_dwordx4 %2, %4, %5 offset:128\n\tglobal_load_dwordx4 %3, %4, %5 offset:192"               \
+                             : "=&v"(X[0]), "=&v"(X[1]), "=&v"(X[2]), "=&v"(X[3]) : "v"(xoff), "s"(ctile) : "memory");              \
+                xoff += step16;                                                                                                     \
+            } while (0)
+    #define KEMR_XPASS(MI, X, VM)                                                                                                   \
+            do {                                                                                                                    \
+                asm volatile("s_waitcnt vmcnt(" #VM ")" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]) :: "memory");               \
+                _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[MI][ni] += X[ni];                                              \
+                asm volatile("global_store_dwordx4 %0, %1, %5 nt\n\tglobal_store_dwordx4 %0, %2, %5 offset:64 nt\n\t"              \
+                             "global_store_dwordx4 %0, %3, %5 offset:128 nt\n\tglobal_store_dwordx4 %0, %4, %5 offset:192 nt\n\ts_nop 1" \
+                             :: "v"(soff), "v"(acc[MI][0]), "v"(acc[MI][1]), "v"(acc[MI][2]), "v"(acc[MI][3]), "s"(ctile) : "memory"); \
+                soff += step16;                                                                                                     \
+            } while (0)
+            // VMEM order: L0 L1 | S0 L2 | S1 L3 | S2 L4 | S3 L5 | S4 L6 | S5 L7 | S6 | S7   (L = 4 loads, S = 4 stores)
+            KEMR_XLOAD4(xa); KEMR_XLOAD4(xb);
+            KEMR_XPASS(0, xa, 4); KEMR_XLOAD4(xa);
+            KEMR_XPASS(1, xb, 8); KEMR_XLOAD4(xb);
+            KEMR_XPASS(2, xa, 8); KEMR_XLOAD4(xa);
+            KEMR_XPASS(3, xb, 8); KEMR_XLOAD4(xb);
+            KEMR_XPASS(4, xa, 8); KEMR_XLOAD4(xa);
+            KEMR_XPASS(5, xb, 8); KEMR_XLOAD4(xb);
+            KEMR_XPASS(6, xa, 8);
+            KEMR_XPASS(7, xb, 4);
+    #undef KEMR_XLOAD4
+    #undef KEMR_XPASS
         } else {
             // ---- epilogue (lane constants behind an opaque copy of `lane`: recomputed here, not kept across the K loop)
             // CONC: both halves run their epilogues in the SAME barrier interval (as the similarity scans do): the leading half
@@ -903,19 +1060,19 @@ static int gemm256u_num_cu(int* out) {
 }
 
 // what the kernel's tile table and 32-bit tile offsets can hold (everything the encoders launch is far inside)
-bool gemm256u_fits(const GemmParams& p, int elem_size) {
+bool gemm256u_fits(const GemmParams& p, int elem_size, int c_elem_size) {
     int num_cu = 0;
     if (gemm256u_num_cu(&num_cu) != KEMR_OK || num_cu <= 0) return false;
     const long tiles = (long)((p.M + 255) / 256) * (p.N / 256);
     const long grid = tiles < num_cu ? tiles : num_cu;
     const long rows = (long)((p.M + 255) / 256) * 256;
     return (tiles + grid - 1) / grid <= GEMM256U_MAX_TILES_PER_WG && rows * p.lda * elem_size < (1L << 32) &&
-           (long)p.N * p.ldw * elem_size < (1L << 32) && rows * p.ldc * 2 < (1L << 32);
+           (long)p.N * p.ldw * elem_size < (1L << 32) && rows * p.ldc * c_elem_size < (1L << 32);
 }
 
-template <int EPI, bool FP8, bool DBG, bool CONC>
+template <int EPI, bool FP8, bool DBG, bool CONC, bool KL = false>
 static int launch256u_a(const GemmParams& p, hipStream_t stream) {
-    auto kern = gemm256u_bf16_nt_kernel<EPI, FP8, DBG, 0, CONC>;
+    auto kern = gemm256u_bf16_nt_kernel<EPI, FP8, DBG, 0, CONC, KL>;
     static int attr_dev = -1;
     int dev = 0, num_cu = 0;
     KEMR_CHECK_HIP(hipGetDevice(&dev));
@@ -924,7 +1081,7 @@ static int launch256u_a(const GemmParams& p, hipStream_t stream) {
         KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PSMEM));
         attr_dev = dev;
     }
-    if (!gemm256u_fits(p, FP8 ? 1 : 2)) KEMR_FAIL(KEMR_ERR_INVALID, "gemm256u: M=%d N=%d K=%d is beyond the persistent kernel's tile table / 32-bit tile offsets", p.M, p.N, p.K);
+    if (!gemm256u_fits(p, FP8 ? 1 : 2, EPI == EPI_BIAS_RESID_F32 ? 4 : 2)) KEMR_FAIL(KEMR_ERR_INVALID, "gemm256u: M=%d N=%d K=%d is beyond the persistent kernel's tile table / 32-bit tile offsets", p.M, p.N, p.K);
     const int tiles = ((p.M + 255) / 256) * (p.N / 256);
     const int grid = tiles < num_cu ? tiles : num_cu;
     GemmParams q = p;
@@ -943,12 +1100,23 @@ static int launch256u(const GemmParams& p, hipStream_t stream) {
     // Epilogues of the two halves in one barrier interval: measured (round 2, same device, sustained) +1.8 % on fc1 + QuickGELU
     // (the VALU-heavy epilogue: 11.1 k -> 9.2 k cycles per tile for both halves), +-0 on the plain store epilogue (single-
     // buffered 3.3 k for both against 2.1 k + 2.9 k one after the other).  g_gemm_conc: 0 never, 1 always, 2 = where it pays.
-    if (g_gemm_conc == 1 || (g_gemm_conc == 2 && EPI == EPI_BIAS_QGELU_BF16)) {
-        if (g_gemm_dbg && !FP8) return launch256u_a<EPI, false, true, true>(p, stream);
-        return launch256u_a<EPI, FP8, false, true>(p, stream);
+    const bool conc = g_gemm_conc == 1 || (g_gemm_conc == 2 && EPI == EPI_BIAS_QGELU_BF16);
+    if constexpr (FP8) {
+        if (conc) return launch256u_a<EPI, true, false, true>(p, stream);
+        return launch256u_a<EPI, true, false, false>(p, stream);
+    } else {
+        if (g_gemm_dbg) {                         // tools/: the stamped / timing-experiment instantiation, for either K loop
+            if (g_gemm_kl) return launch256u_a<EPI, false, true, false, true>(p, stream);
+            if (conc) return launch256u_a<EPI, false, true, true>(p, stream);
+            return launch256u_a<EPI, false, true, false>(p, stream);
+        }
+        if (g_gemm_kl) {                          // tools/: the long-interval K loop for A/B timing
+            if (conc) return launch256u_a<EPI, false, false, true, true>(p, stream);
+            return launch256u_a<EPI, false, false, false, true>(p, stream);
+        }
+        if (conc) return launch256u_a<EPI, false, false, true>(p, stream);
+        return launch256u_a<EPI, false, false, false>(p, stream);
     }
-    if (g_gemm_dbg && !FP8) return launch256u_a<EPI, false, true, false>(p, stream);
-    return launch256u_a<EPI, FP8, false, false>(p, stream);
 }
 
 // tools/ only: the stamp sums of the last DBG launch with flag 64 (per workgroup: 8 K-loop intervals, K-loop tail, epilogue,
@@ -980,9 +1148,9 @@ static int sim_chunking(int nq, int ng, int kdim, long long gallery_offset, int*
     return (g_tiles + *tpc_out - 1) / *tpc_out;
 }
 
-template <int SIM, bool DBG>
+template <int SIM, bool DBG, bool KL = false>
 static int launch_sim_mode_a(const GemmParams& p, int q_tiles, hipStream_t stream) {
-    auto kern = gemm256u_bf16_nt_kernel<EPI_BIAS_BF16, false, DBG, SIM>;
+    auto kern = gemm256u_bf16_nt_kernel<EPI_BIAS_BF16, false, DBG, SIM, false, KL>;
     static int attr_dev = -1;
     int dev = 0;
     KEMR_CHECK_HIP(hipGetDevice(&dev));
@@ -1005,6 +1173,9 @@ template <int SIM>
 static int launch_sim_mode(const GemmParams& p, int q_tiles, hipStream_t stream) {
     if constexpr (SIM != 3) {
         if (g_gemm_dbg & (64 | 128)) return launch_sim_mode_a<SIM, true>(p, q_tiles, stream);      // tools: stamped instantiation
+    }
+    if constexpr (SIM == 2) {
+        if (g_gemm_kl) return launch_sim_mode_a<SIM, false, true>(p, q_tiles, stream);      // tools/: long-interval K loop, A/B timing
     }
     return launch_sim_mode_a<SIM, false>(p, q_tiles, stream);
 }
@@ -1087,8 +1258,11 @@ int launch_gemm256u(const GemmParams& p, int epi, hipStream_t stream) {
         case EPI_BIAS_BF16:       return launch256u<EPI_BIAS_BF16, false>(p, stream);
         case EPI_BIAS_QGELU_BF16: return launch256u<EPI_BIAS_QGELU_BF16, false>(p, stream);
         case EPI_BIAS_RESADD_BF16: return launch256u_a<EPI_BIAS_RESADD_BF16, false, false, false>(p, stream);
+        case EPI_BIAS_RESID_F32:
+            if (g_gemm_kl) return launch256u_a<EPI_BIAS_RESID_F32, false, false, false, true>(p, stream);
+            return launch256u_a<EPI_BIAS_RESID_F32, false, false, false>(p, stream);
     }
-    KEMR_FAIL(KEMR_ERR_INVALID, "gemm256u: epilogue %d is not a bf16-store epilogue", epi);
+    KEMR_FAIL(KEMR_ERR_INVALID, "gemm256u: epilogue %d is not one of this kernel's", epi);
 }
 
 // fp8 e4m3 operands: A [ceil256(M), lda] and W [N, ldw] in bytes, K % 128 == 0, K >= 256, N % 256 == 0; p.wscale[N] scales the

@@ -14,6 +14,7 @@
 // Per (query, gallery chunk) partial lists go to the workspace and are merged by topk_merge_kernel, the same
 // kernel that merges per-GPU shards.  Order rule everywhere: higher score first, then lower candidate id.
 #include "common.h"
+#include "../../include/kemr_debug.h"
 #include <cmath>
 #include <vector>
 
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(256) void simk_select_kernel(const float* __restric
     }
 }
 
-static int g_sim_lists = 1;
+namespace kemr { int g_sim_lists = 1; }
 
 static int sim_chunks(int nq, int ng, int* tiles_per_chunk) {
     const int q_tiles = (nq + ST - 1) / ST, g_tiles = (ng + ST - 1) / ST;
@@ -759,12 +760,6 @@ extern "C" int kemr_debug_sim_lists(const void* workspace_dev, int nq, int ng, i
 
 // tools / tests: 0 = always sim_kernel, 1 = candidate lists where they apply (default), 2 = lists AND the fallback forced to
 // run after them (its result overwrites theirs: exercises the overflow route)
-extern "C" int kemr_set_sim_lists(int mode) {
-    if (mode < 0 || mode > 2) KEMR_FAIL(KEMR_ERR_INVALID, "set_sim_lists: mode %d not in 0..2", mode);
-    g_sim_lists = mode;
-    return KEMR_OK;
-}
-
 extern "C" int kemr_scores_dense(const void* q_panel_dev, int nq, const void* g_panel_dev, int ng, int64_t kdim,
                                  float* out_dev, int64_t ld_out, void* stream) {
     KEMR_TRY(check_panels(q_panel_dev, nq, g_panel_dev, ng, kdim));

@@ -51,8 +51,9 @@ class ClipEngine:
     """One packed CLIP model (both towers) in HBM."""
 
     def __init__(self, arch: ClipArch, device: torch.device | str = "cuda:0", precision: str = _lib.DEFAULT_PRECISION):
-        """precision: "bf16-res16" (default: bf16 residual stream), "bf16" (fp32 residual stream), "fp8" (QKV GEMMs on fp8
-        operands, BASELINE config 5) or "fp8-mlp" (fc1 too); see kemr_precision in include/kemr.h."""
+        """precision: "bf16" (default: bf16 operands, fp32 accumulation, fp32 residual stream), "bf16-res16" (bf16 residual
+        stream, opt-in), "fp8" (QKV GEMMs on fp8 operands, BASELINE config 5), "fp8-res16" or "fp8-mlp" (fc1 too); see
+        kemr_precision in include/kemr.h."""
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
         self.precision = precision
@@ -75,6 +76,22 @@ class ClipEngine:
                 self._L.kemr_model_destroy(h)
             except Exception:
                 pass
+
+    def set_residual_fusion(self, level) -> None:
+        """Option "residual_fusion" of THIS model (include/kemr.h kemr_model_set_option): 0 / False = the out-proj / fc2 GEMMs store
+        bf16 updates that the LayerNorms apply; 1 / True = bf16 residual streams add them in the GEMM epilogues (default); 2 = fp32
+        residual streams too (nothing is rounded; slower)."""
+        _lib.check(self._L.kemr_model_set_option(self._h, b"residual_fusion", int(level)), "model_set_option")
+
+    def residual_fusion(self) -> int:
+        """The option's value (0 / 1 / 2)."""
+        v = C.c_int(0)
+        _lib.check(self._L.kemr_model_get_option(self._h, b"residual_fusion", C.byref(v)), "model_get_option")
+        return v.value
+
+    def residual_fusion_active(self) -> bool:
+        """Whether large calls of THIS engine add the residual inside the GEMM epilogues (option and stream type together)."""
+        return self.residual_fusion() >= (1 if self.precision.endswith("res16") else 2)
 
     # ------------------------------------------------------------------ weights
     def tensor_names(self) -> Sequence[str]:
@@ -212,16 +229,15 @@ def pair_scores(qp: Panel, gp: Panel, q_rows: torch.Tensor, g_rows: torch.Tensor
     return out
 
 
-_last_sim_ws = None
-
-
 def sim_topk(qp: Panel, gp: Panel, k: int, gallery_offset: int = 0,
              gt_idx: Optional[torch.Tensor] = None, gt_score: Optional[torch.Tensor] = None,
              ahead: Optional[torch.Tensor] = None,
-             bonus: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
-             ) -> Tuple[torch.Tensor, torch.Tensor]:
+             bonus: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None,
+             return_workspace: bool = False):
     """Fused scores + top-k (+ `ahead` counts when a ground truth is given). Returns (scores [nq,k], ids [nq,k]).
-    k == 0 = rank only (needs the ground truth; the returned tensors are empty)."""
+    k == 0 = rank only (needs the ground truth; the returned tensors are empty).  return_workspace (tools/): the call's
+    scratch tensor as a third result (debug.sim_lists reads the candidate-list statistics out of it); otherwise the scratch
+    goes back to the caching allocator with the call (2.3 GB at 43 k x 43 k)."""
     L = _lib.lib()
     if qp.kdim != gp.kdim:
         raise RuntimeError(f"sim_topk: panel kdim mismatch ({qp.kdim} vs {gp.kdim})")
@@ -234,8 +250,6 @@ def sim_topk(qp: Panel, gp: Panel, k: int, gallery_offset: int = 0,
     if ng == 0:
         return top_s.fill_(float("-inf")), top_i.fill_(-1)
     ws = torch.empty(max(int(L.kemr_sim_workspace_bytes(nq, ng, qp.kdim, k)), 256), dtype=torch.uint8, device=dev)
-    global _last_sim_ws
-    _last_sim_ws = ws           # tools/bench_sim.py reads the candidate-list statistics out of it (kemr_debug_sim_lists)
     if gt_idx is not None:
         if gt_score is None or ahead is None:
             raise RuntimeError("sim_topk: gt_idx needs gt_score and ahead")
@@ -258,6 +272,8 @@ def sim_topk(qp: Panel, gp: Panel, k: int, gallery_offset: int = 0,
                                    _opt_ptr(gt_idx), _opt_ptr(gt_score), _opt_ptr(ahead),
                                    _opt_ptr(b_ptr), _opt_ptr(b_col), _opt_ptr(b_val),
                                    C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(_stream_ptr(dev))), "sim_topk")
+    if return_workspace:
+        return top_s, top_i, ws
     return top_s, top_i
 
 
@@ -320,15 +336,9 @@ def rank_dense(scores: torch.Tensor, gt_idx: Optional[torch.Tensor] = None, k: i
 
 # ---------------------------------------------------------------------- per-kernel hooks used by tests
 def set_gemm_variant(variant: int) -> None:
-    """0 = automatic tile choice, 1 = force 128x128, 2 = force 256x256 where N % 256 == 0 (tests / A-B benchmarks)."""
-    _lib.check(_lib.lib().kemr_set_gemm_variant(variant), "set_gemm_variant")
-
-
-def set_residual_fusion(on: bool) -> None:
-    """bf16 residual streams: add the residual inside the out-proj / fc2 GEMM epilogues (default, env KEMR_RESADD=0 turns it
-    off) or keep the store-only epilogues with the updates applied by the LayerNorms (one rounding of x per layer instead of
-    two, 3.7 % slower)."""
-    _lib.check(_lib.lib().kemr_set_gemm_variant((2 if on else 1) << 28), "set_residual_fusion")
+    """tools/ and tests/: see debug.set_gemm_variant (include/kemr_debug.h; nothing in the product path calls this)."""
+    from . import debug
+    debug.set_gemm_variant(variant)
 
 
 def op_gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], m: int, epilogue: int,

@@ -171,25 +171,30 @@ def test_fp8_encoders_match_oracle(device, name, nimg, ntxt, precision, tol):
     assert float((1 - ci).max()) < tol and float((1 - ct).max()) < tol
 
 
-def test_residual_fusion_switch(device):
-    """bf16 residual stream: residual add inside the out-proj / fc2 epilogues (default) against the store-only epilogues +
-    LayerNorm updates: both inside the path's bar against the oracle, close to each other, and the switch really switches."""
-    arch, sd, eng = _engine("ViT-B/32", device, precision="bf16-res16")
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_residual_fusion_switch(device, precision):
+    """Option "residual_fusion" (per model): residual add inside the out-proj / fc2 epilogues (default) against the store-only
+    epilogues + LayerNorm updates: both inside the path's bar against the oracle, close to each other, the switch really
+    switches, and it is THIS model's switch -- a second engine keeps its own setting."""
+    arch, sd, eng = _engine("ViT-B/32", device, precision=precision)
+    other = engine.ClipEngine(arch, device, precision=precision)
+    other.load_state_dict(sd)
     oa = clip_ref.ARCHS["ViT-B/32"]
     g = torch.Generator().manual_seed(77)
     px = torch.randn(40, 3, arch.image_size, arch.image_size, generator=g)            # 2 000 token rows: the persistent GEMM's side of the switch
     ids = clip_ref.synthetic_ids(oa, 24)
     ref_i, ref_t = clip_ref.encode_image(sd, oa, px[:4]), clip_ref.encode_text(sd, oa, ids[:4])
+    assert eng.residual_fusion() and other.residual_fusion()
     outs = {}
-    try:
-        for on in (True, False):
-            engine.set_residual_fusion(on)
-            outs[on] = (eng.encode_image(px.to(device)).cpu(), eng.encode_text(ids.to(device)).cpu())
-            assert float((1 - _cos(outs[on][0][:4], ref_i)).max()) < COS_TOL and float((1 - _cos(outs[on][1][:4], ref_t)).max()) < COS_TOL
-    finally:
-        engine.set_residual_fusion(True)
+    for on in (True, False):
+        eng.set_residual_fusion(on)
+        assert eng.residual_fusion() == on and other.residual_fusion()
+        outs[on] = (eng.encode_image(px.to(device)).cpu(), eng.encode_text(ids.to(device)).cpu())
+        assert float((1 - _cos(outs[on][0][:4], ref_i)).max()) < COS_TOL and float((1 - _cos(outs[on][1][:4], ref_t)).max()) < COS_TOL
+    assert torch.equal(other.encode_image(px.to(device)).cpu(), outs[True][0])          # untouched by eng's switch
     assert not torch.equal(outs[True][0], outs[False][0])
-    assert float((1 - _cos(outs[True][0], outs[False][0])).max()) < 3e-4 and float((1 - _cos(outs[True][1], outs[False][1])).max()) < 3e-4
+    close = 3e-4 if precision == "bf16-res16" else 2e-5
+    assert float((1 - _cos(outs[True][0], outs[False][0])).max()) < close and float((1 - _cos(outs[True][1], outs[False][1])).max()) < close
 
 
 def test_fp8_recall_at_10_within_0p2_percent_of_bf16(device):

@@ -19,12 +19,13 @@ def _bf16_round(x):
 def test_gemm_epilogues(device, m, n, k, epi, variant):
     engine.set_gemm_variant(variant)      # 1: 128x128 tiles, 2: 256x256 tiles (every N here is a multiple of 256)
     try:
-        _gemm_epilogue_case(device, m, n, k, epi)
+        # the persistent kernel (variant 7, more than 512 rows) stores whole 256-row tiles: C's pad rows are scratch
+        _gemm_epilogue_case(device, m, n, k, epi, pad_rows_kept=not (variant == 7 and m > 512))
     finally:
         engine.set_gemm_variant(0)
 
 
-def _gemm_epilogue_case(device, m, n, k, epi):
+def _gemm_epilogue_case(device, m, n, k, epi, pad_rows_kept=True):
     g = torch.Generator().manual_seed(m * 7 + n + k + epi)
     m_alloc = (m + 255) // 256 * 256
     a = torch.randn(m_alloc, k, generator=g)
@@ -45,7 +46,7 @@ def _gemm_epilogue_case(device, m, n, k, epi):
     tol = 2e-2 if epi != _lib.EPI_BIAS_RESID_F32 else 2e-4    # bf16 output rounding vs fp32 output
     err = (got[:m] - ref).abs()
     assert float((err / (ref.abs() + 1.0)).max()) < tol
-    if epi == _lib.EPI_BIAS_RESID_F32:                        # rows >= m are never written
+    if epi == _lib.EPI_BIAS_RESID_F32 and pad_rows_kept:      # rows >= m are never written (tile kernels with row masks)
         assert torch.equal(got[m:], c0[m:])
     # bf16 epilogues: rows in [m, m_alloc) are scratch (the persistent kernel stores whole tiles)
 
@@ -232,6 +233,44 @@ def test_gemm_residual_add_epilogue(device, m, n, k):
         want = (delta[:m].float() + want.float()).to(torch.bfloat16)
     with pytest.raises(RuntimeError):
         engine.op_gemm(a[:256], w, bias, 100, _lib.EPI_BIAS_RESADD_BF16, c=x[:256].clone())      # too few rows for the persistent kernel
+
+
+@pytest.mark.parametrize("kl", [1, 0])
+@pytest.mark.parametrize("m,n,k", [(65535, 1024, 4096), (65535, 1024, 1024), (65527, 768, 3072), (1000, 256, 128)])
+def test_gemm_residual_epilogues_against_fp32_torch(device, m, n, k, kl):
+    """Both in-place residual epilogues of the persistent kernel at the towers' own shapes (fc2 of ViT-L/14 at B = 255: 65 535 x
+    1 024 x 4 096, out-proj, the 851-text fc2) against an INDEPENDENT fp32 statement of the op (torch fp32 matmul of the same bf16
+    operands): EPI_BIAS_RESID_F32 x += A.W^T + b exactly in fp32 (no rounding but the accumulation order), EPI_BIAS_RESADD_BF16
+    within the two bf16 roundings it documents.  Both K loops (debug switch gemm_kl: four / eight barrier intervals per K-tile)."""
+    from knowledge_enhanced_multimodal_retrieval_amd import debug
+    g = torch.Generator(device=device).manual_seed(m + n + k)
+    ma = (m + 255) // 256 * 256
+    a = torch.randn(ma, k, generator=g, device=device).to(torch.bfloat16)
+    w = (torch.randn(n, k, generator=g, device=device) * k ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(n, generator=g, device=device)
+    x0 = torch.randn(ma, n, generator=g, device=device) * 3
+    prev = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        upd = a[:m].float() @ w.float().t() + bias                   # fp32 reference of the update
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = prev
+    with debug.override(gemm_variant=7, gemm_kl=kl):
+        x = x0.clone()
+        engine.op_gemm(a, w, bias, m, _lib.EPI_BIAS_RESID_F32, c=x)
+        err = (x[:m] - (x0[:m] + upd)).abs().max().item()
+        assert err < 2e-5 * k ** 0.5 + 1e-5, (err, "resid f32")      # fp32 accumulation over k terms of size ~k^-1/2 each
+        engine.op_gemm(a, w, bias, m, _lib.EPI_BIAS_RESID_F32, c=x)  # in place, second round
+        err = (x[:m] - (x0[:m] + 2 * upd)).abs().max().item()
+        assert err < 4e-5 * k ** 0.5 + 2e-5, (err, "resid f32 x2")
+        xb = x0.to(torch.bfloat16)
+        want = (upd.to(torch.bfloat16).float() + xb[:m].float()).to(torch.bfloat16)
+        got = xb.clone()
+        engine.op_gemm(a, w, bias, m, _lib.EPI_BIAS_RESADD_BF16, c=got)
+        # one bf16 ulp where the fp32 accumulation order moved a value across a rounding boundary, nothing beyond
+        d = (got[:m].float() - want.float()).abs()
+        assert float((d / (want.float().abs() + 1.0)).max()) < 1.6e-2
+        assert float((d > 0).float().mean()) < 0.02
 
 
 def test_gemm_rejects_bad_shapes(device):

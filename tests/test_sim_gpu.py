@@ -266,7 +266,8 @@ def test_rank_only_fast_path_matches_counting_rule(device, nq, ng, d, terms, off
 
 
 def _lists_mode(mode):
-    _lib.check(_lib.lib().kemr_set_sim_lists(mode), "set_sim_lists")
+    from knowledge_enhanced_multimodal_retrieval_amd import debug
+    debug.set("sim_lists", mode)
 
 
 @pytest.mark.parametrize("nq,ng,d,terms,off,k", [(300, 9000, 128, 1, 0, 10), (257, 16000, 128, 1, 5, 5), (600, 20001, 192, 3, 1000, 32),

@@ -14,7 +14,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from knowledge_enhanced_multimodal_retrieval_amd import _lib, engine  # noqa: E402
+from knowledge_enhanced_multimodal_retrieval_amd import _lib, debug, engine  # noqa: E402
 
 
 def main():
@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--routes", default="0,1")
+    ap.add_argument("--kl", default="1", help="K loops of the list pass to time, e.g. 0,1 (debug switch gemm_kl)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--stamps", action="store_true", help="in-kernel cycle split of the list pass (stamped instantiation)")
     ap.add_argument("--device-rng", action="store_true", help="the data bench.py uses (device generator, seed 7)")
@@ -46,13 +47,14 @@ def main():
     sgt = engine.pair_scores(qp, gp, torch.arange(args.nq, device=dev).int(), gt)
     flops = 2.0 * args.nq * args.ng * qp.kdim
     ref = None
-    for route in [int(r) for r in args.routes.split(",")]:
-        _lib.check(_lib.lib().kemr_set_sim_lists(route), "set_sim_lists")
+    for route, kl in [(int(r), int(q)) for r in args.routes.split(",") for q in args.kl.split(",")]:
+        debug.set("sim_lists", route)
+        debug.set("gemm_kl", kl)
         for with_rank in (False, True):
             def run():
                 ahead = torch.zeros(args.nq, dtype=torch.int32, device=dev) if with_rank else None
-                return engine.sim_topk(qp, gp, args.k, 0, gt if with_rank else None, sgt if with_rank else None, ahead), ahead
-            (s, i), ahead = run()
+                return engine.sim_topk(qp, gp, args.k, 0, gt if with_rank else None, sgt if with_rank else None, ahead, return_workspace=True), ahead
+            (s, i, ws), ahead = run()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.iters):
@@ -62,19 +64,17 @@ def main():
             if ref is None:
                 ref = (s, i)
             same = bool(torch.equal(s, ref[0]) and torch.equal(i, ref[1]))
-            import ctypes as C
-            st = (C.c_int32 * 6)()
-            _lib.check(_lib.lib().kemr_debug_sim_lists(C.c_void_p(engine._last_sim_ws.data_ptr()), args.nq, args.ng, qp.kdim, args.k,
-                                                       C.cast(st, C.c_void_p)), "debug_sim_lists")
-            print(json.dumps({"route": route, "with_rank": with_rank, "ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 1),
+            st = debug.sim_lists(ws, args.nq, args.ng, qp.kdim, args.k)
+            print(json.dumps({"route": route, "kl": kl, "with_rank": with_rank, "ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 1),
                               "same_as_first": same, "nq": args.nq, "ng": args.ng, "kdim": qp.kdim, "k": args.k,
                               "lists": dict(zip(("flag", "longest", "cap", "chunks", "sampled", "records_per_query"), list(st)))}))
-    _lib.check(_lib.lib().kemr_set_sim_lists(1), "set_sim_lists")
+    debug.set("sim_lists", 1)
+    debug.set("gemm_kl", 1)
     if args.stamps:
         import ctypes as C
         import numpy as np
         for label, k, rank in (("rank only (SIM 1)", 0, True), ("lists + rank (SIM 2)", args.k, True), ("lists (SIM 2)", args.k, False)):
-            engine.set_gemm_variant(64 << 8)
+            debug.set("gemm_flags", 64)
             ahead = torch.zeros(args.nq, dtype=torch.int32, device=dev)
             for _ in range(3):
                 if rank:
@@ -84,7 +84,7 @@ def main():
             torch.cuda.synchronize()
             buf = (C.c_uint * (1024 * 16))()
             _lib.check(_lib.lib().kemr_debug_gemm_stamps(buf, 1024 * 16), "stamps")
-            engine.set_gemm_variant(0)
+            debug.set("gemm_flags", 0)
             st = np.frombuffer(buf, dtype=np.uint32).reshape(1024, 16).astype(np.float64)[:256]
             tiles, nt = st[:, 14], st[:, 15]
             per_ktile = st[:, :8] / (tiles * nt)[:, None]
