@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--resadd", type=int, default=-1, help="A/B: 1 / 0 = residual add inside the out-proj / fc2 epilogues on / off (default: the library's setting)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sim", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the host-pipeline sub-result (N = 1: uint8 sources through encode_dataset)")
+    ap.add_argument("--pipeline-items", type=int, default=8160, help="gallery items of the host-pipeline sub-result")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp8 / bf16-res16 sub-results (two more engines, ~20 steps each)")
     args = ap.parse_args()
 
@@ -240,10 +242,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     out = main_steps.check_outputs()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    def max_over_ranks(x: float) -> float:
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if os.environ.get("KEMR_DIST_BACKEND") == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    elapsed = max_over_ranks(elapsed)
     assert all(torch.isfinite(o).all().item() for o in out)
 
     rccl_ranks = dist.get_world_size() if dist is not None else 1
@@ -311,6 +317,35 @@ def main():
     result["kernel_ms_per_step"] = {"gemm": ms[0], "layernorm": ms[1], "attention": ms[2], "embed_tail": ms[3]}
     result["config"]["residual_add_in_gemm_epilogue"] = resadd_on
 
+    # ------------------------------------------------------------------ the same encode through the host input pipeline
+    # camera-sized uint8 sources -> CLIPEvalDatasetHF(split, preprocess), the reference's own dataset call
+    # (evaluator.py:330-333), with the preprocess object clip.load returns -> DataLoader workers (decode stand-in, tokenise, pack) ->
+    # one pinned H2D copy + one preprocess launch pair per loader batch -> the three encoders (evaluators.encode_dataset, what the
+    # drop-in CLIs run).  PCIe-inclusive by construction; worker start-up is inside the timed region.  N = 1 only.
+    if world == 1 and not args.no_pipeline and args.model == "ViT-L/14":
+        import warnings
+        from knowledge_enhanced_multimodal_retrieval_amd import clip_api, datasets as kds, evaluators, tokenizer
+        clip_api.allow_random_weights(True)
+        tokenizer.allow_hash_tokenizer(True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            pm, ppre = clip_api.load(args.model, device=str(dev))
+        n_pipe, workers = args.pipeline_items, evaluators.default_loader_workers()
+        split = kds.SyntheticHFSplit(n_pipe, 11)
+        evaluators.encode_dataset(pm, kds.CLIPEvalDatasetHF(kds.SyntheticHFSplit(510, 12), ppre), 64, 1, 0)      # warm: kernels, workspaces
+        barrier()
+        t1 = time.perf_counter()
+        pi, pq, pt, pids = evaluators.encode_dataset(pm, kds.CLIPEvalDatasetHF(split, ppre), 64, 1, workers)
+        barrier()
+        dtp = time.perf_counter() - t1
+        assert pi.shape[0] == n_pipe and len(pids) == n_pipe and bool(torch.isfinite(pi).all())
+        result["pipeline"] = {"items_per_s": 3 * n_pipe / dtp, "images_per_s": n_pipe / dtp, "seconds": dtp, "items": n_pipe,
+                              "loader_workers": workers, "loader_batch": 64, "host_cores": os.cpu_count(),
+                              "image_transform": "gpu" if ppre.defer_to_gpu else "host",
+                              "source": "uint8 PIL images of 8 camera-like sizes (224x224 .. 600x800) -> CLIPEvalDatasetHF(split, preprocess) -> "
+                                        "evaluators.encode_dataset; worker start-up and PCIe included"}
+        del pm, pi, pq, pt
+
     # ------------------------------------------------------------------ similarity + top-10 on the 43k gallery
     if not args.no_sim:
         per = (GALLERY + world - 1) // world
@@ -325,55 +360,43 @@ def main():
         # Recall@K / MRR metrics need)
         cases = (("q1024_bf16", 1024, 1, 1, 10), ("q43000_bf16", GALLERY, 1, 1, 10), ("q43000_bf16_rank_only", GALLERY, 1, 1, 0),
                  ("q43000_fp32x3", GALLERY, 3, 1, 10), ("q43000_bf16_c3_fused_t2i_t2t", GALLERY, 1, 2, 10))
+        from knowledge_enhanced_multimodal_retrieval_amd import dist as kdist
         for label, nq, terms, parts, k in cases:
+            # The product class at every N: dist.ShardedGallery holds this rank's shard of the gallery; a search is
+            # all-gather of the ranks' query slices -> local fused top-k with global ids -> all-gather + merge of the candidates,
+            # ranks add the all-reduced ground-truth score and `ahead` counts (no collective at all when world == 1).
             gparts = [gal_all[lo:hi]] + ([tgt_all[lo:hi]] if parts == 2 else [])
-            gp = engine.build_panel(gparts, _lib.SIDE_GALLERY, terms)
-            qs = qry_all[:nq]
-            gt = torch.arange(nq, dtype=torch.int32, device=dev)
+            sg = kdist.ShardedGallery(gparts, GALLERY, precision="bf16" if terms == 1 else "fp32x3")
+            sg.check_rows = False                                      # fixed query slices: the call has no host synchronisation
+            nql = nq // world                                          # every rank brings an equal slice of the query batch
+            nq = nql * world
+            qs = qry_all[rank * nql:(rank + 1) * nql]
+            gt = torch.arange(rank * nql, (rank + 1) * nql, dtype=torch.int32, device=dev)
 
             def run():
-                qp = engine.build_panel([qs] * parts, _lib.SIDE_QUERY, terms, part_scale=[1.0 / parts] * parts)   # queries arrive as fp32 embeddings
-                ahead = None
-                if k == 0:                                             # rank of the diagonal ground truth (shard-local part of it)
-                    inside = (gt >= lo) & (gt < hi)
-                    sgt = engine.pair_scores(qp, gp, gt, (gt - lo).clamp(0, hi - lo - 1))
-                    if dist is not None:                               # the owner shard's score of every query's ground truth
-                        sgt = torch.where(inside, sgt, torch.zeros_like(sgt))
-                        dist.all_reduce(sgt)
-                    ahead = torch.zeros(nq, dtype=torch.int32, device=dev)
-                    engine.sim_topk(qp, gp, 0, lo, gt, sgt, ahead)
-                    if dist is not None:
-                        dist.all_reduce(ahead)
-                    return ahead, None
-                s, i = engine.sim_topk(qp, gp, k, lo)
-                if dist is not None:                                   # exchange step: candidates of every shard, then merge
-                    ss = [torch.empty_like(s) for _ in range(world)]
-                    ii = [torch.empty_like(i) for _ in range(world)]
-                    dist.all_gather(ss, s)
-                    dist.all_gather(ii, i)
-                    s, i = engine.topk_merge(torch.stack(ss, 1), torch.stack(ii, 1), k)
-                return s, i
+                if k == 0:                                             # ranks only (what Recall@K / MRR need)
+                    ranks, _, _ = sg.ranks([qs] * parts, gt, weights=[1.0 / parts] * parts, k=0)
+                    return ranks, None
+                return sg.search([qs] * parts, weights=[1.0 / parts] * parts, k=k)      # queries arrive as fp32 embeddings
 
             run()
             barrier()
             reps = 5 if nq <= 2048 else 3
             t1 = time.perf_counter()
             for _ in range(reps):
-                s, i = run()
+                s_, i_ = run()
             barrier()
             dt = (time.perf_counter() - t1) / reps
-            if dist is not None:
-                tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt = float(tt.item())
+            dt = max_over_ranks(dt)
             kdim = arch.embed_dim * terms * parts
             flops = 2.0 * nq * GALLERY * kdim
-            sim[label] = {"ms": 1e3 * dt, "mfma_tflops_per_gpu": flops / dt / 1e12 / world, "kdim": kdim}
+            sim[label] = {"ms": 1e3 * dt, "mfma_tflops_per_gpu": flops / dt / 1e12 / world, "kdim": kdim, "queries": nq,
+                          "via": "dist.ShardedGallery.%s" % ("ranks" if k == 0 else "search")}
             if k:
-                sim[label]["top1_hit"] = float((i[:, 0].long() == torch.arange(nq, device=dev)).float().mean())
+                sim[label]["top1_hit"] = float((i_[:, 0].long() == torch.arange(nq, device=dev)).float().mean())
             else:
-                sim[label]["rank1"] = float((s == 0).float().mean())
-            del gp
+                sim[label]["rank1"] = float((s_ == 1).float().mean())
+            del sg
         result["sim_top10"] = sim
         # roofline of the similarity kernel at the headline size (MFMA-bound: SURVEY 8(d)); min_bytes = both panels read once +
         # the lists written
@@ -405,10 +428,7 @@ def main():
             barrier()
             dt = time.perf_counter() - t1
             o2 = s2.check_outputs()
-            if dist is not None:
-                tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt = float(tt.item())
+            dt = max_over_ranks(dt)
             cos = [float(torch.nn.functional.cosine_similarity(a.double(), b.double()).min()) for a, b in zip(o2, out)]
             extras[prec] = {"items_per_s": 3 * B * world * n2 / dt, "ms_per_step": 1e3 * dt / n2, "steps": n2,
                             "min_cosine_vs_default_image_query_target": cos}

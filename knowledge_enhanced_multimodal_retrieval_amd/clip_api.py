@@ -22,7 +22,7 @@ import torch
 
 from .clip_module import CLIP, build_model
 from .config import ARCHS, get_arch
-from .preprocess import ClipPreprocess
+from .preprocess import ClipPreprocess, gpu_preprocessing_enabled
 from .tokenizer import tokenize  # noqa: F401  (re-exported)
 
 _PUBLIC = ("ViT-B/32", "ViT-B/16", "ViT-L/14")
@@ -98,4 +98,5 @@ def load(name: str, device: Union[str, torch.device] = "cuda" if torch.cuda.is_a
         warnings.warn(f"clip.load({name!r}): seeded RANDOM weights (explicitly allowed)", RuntimeWarning, stacklevel=2)
         model.weights_source = "random(seed 0)"
     model = model.to(device).eval()
-    return model, ClipPreprocess(get_arch(name).image_size)
+    on_gpu = torch.device(device).type == "cuda"
+    return model, ClipPreprocess(get_arch(name).image_size, defer_to_gpu=on_gpu and gpu_preprocessing_enabled())

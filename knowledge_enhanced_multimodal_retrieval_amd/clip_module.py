@@ -118,14 +118,25 @@ class CLIP(nn.Module):
         return out
 
     def refresh(self) -> None:
-        """Re-pack the current parameter values into the HIP engine (forces what `engine()` detects by itself)."""
+        """Re-pack the current parameter values into the HIP engine at the next encode call.  `engine()` detects by itself what
+        autograd's version counters see -- optimizer.step(), `p.add_()` / `p.copy_()` under no_grad, load_state_dict, .to() --
+        and re-assigned storage.  It does NOT see a write through `p.data` (`p.data.copy_(w)`, `p.data.mul_(d)`: `.data` is a
+        detached alias with a version counter of its own, the parameter's stays put -- EMA and hand-rolled weight loading do
+        this): call `refresh()` after such a write, or set KEMR_WEIGHT_DIGEST=1, which adds a content digest (one fused norm
+        over all parameters and one host read, about 0.1 ms) to every `engine()` call."""
         self._dirty = True
 
     def _fingerprint(self):
-        """Cheap identity of the parameter values: in-place edits (optimizer.step(), p.data.copy_(), p.add_()) bump a
-        tensor's version counter, re-assignment changes its storage.  The reference's trainer validates through
-        `evaluate_clip_model_for_training` right after optimizer.step() (train/trainer.py:241)."""
-        return tuple((p._version, p.data_ptr()) for p in self.parameters())
+        """Cheap identity of the parameter values: in-place edits of the parameter itself (optimizer.step(), `p.add_()`,
+        `p.copy_()`) bump its version counter, re-assignment changes its storage; see `refresh()` for what this misses.  The
+        reference's trainer validates through `evaluate_clip_model_for_training` right after optimizer.step()
+        (train/trainer.py:241)."""
+        fp = tuple((p._version, p.data_ptr()) for p in self.parameters())
+        if os.environ.get("KEMR_WEIGHT_DIGEST", "") == "1":
+            params = [p.detach() for p in self.parameters()]
+            digest = torch.stack(torch._foreach_norm(params)).double().cpu()       # content digest: catches writes through .data
+            fp = fp + (tuple(digest.tolist()),)
+        return fp
 
     def __deepcopy__(self, memo):
         """The packed engine is a raw library handle: a copy gets its own, built lazily (never two owners of one handle)."""
@@ -149,7 +160,7 @@ class CLIP(nn.Module):
             raise RuntimeError("CLIP: the model sits on %s; the encoders run only on a GPU (model.to('cuda')); there is no "
                                "CPU fallback" % dev)
         if self._engine is None or self._engine.device != dev:
-            # encoder precision of the packed copy: "bf16-res16" unless KEMR_PRECISION says otherwise (bf16 | fp8 | fp8-mlp,
+            # encoder precision of the packed copy: "bf16" (fp32 residual stream) unless KEMR_PRECISION says otherwise (bf16-res16 | fp8 | fp8-res16 | fp8-mlp,
             # kemr_precision in include/kemr.h) -- an environment switch so that the reference's scripts stay unchanged
             self._engine, self._dirty = ClipEngine(self.arch, dev, precision=os.environ.get("KEMR_PRECISION", _lib_default_precision())), True
         fp = self._fingerprint()

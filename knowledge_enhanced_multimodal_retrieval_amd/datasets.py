@@ -25,7 +25,14 @@ class CLIPEvalDatasetHF(Dataset):
     def __init__(self, hf_dataset, preprocessor=None, max_text_length: int = 150, image_size: int = 224):
         self.dataset, self.preprocessor = hf_dataset, preprocessor
         self.max_text_length, self.image_size = max_text_length, image_size
-        logger.info(f"Evaluation dataset initialized: {len(self.dataset)} samples")
+        # The preprocess object of clip.load / load_clip_model may say "defer to the GPU" (preprocess.ClipPreprocess): the item is
+        # then the decoded image as uint8 [H, W, 3]; collate_fn_eval packs a batch of them and evaluators.encode_dataset runs the
+        # transform on the device, bit-identical to the host one.  The reference's call site stays as it is.
+        if getattr(preprocessor, "defer_to_gpu", False):
+            from .preprocess import RawRGB
+            self.host_preprocessor, self.preprocessor = preprocessor, RawRGB()
+        logger.info(f"Evaluation dataset initialized: {len(self.dataset)} samples"
+                    + (" (image transform on the GPU)" if getattr(preprocessor, "defer_to_gpu", False) else ""))
 
     def __len__(self):
         return len(self.dataset)
@@ -80,6 +87,23 @@ class SyntheticRetrievalDataset(Dataset):
         query = " ".join(shared[:2] + pick(int(torch.randint(3, 12, (1,), generator=g))))
         target = " ".join(shared + pick(int(torch.randint(10, 40, (1,), generator=g))))
         return image, query, target, f"synthetic-{idx:06d}"
+
+
+class SyntheticHFSplit:
+    """A stand-in for one split of the HuggingFace dataset the reference loads (columns image / query_text / target_text /
+    uuid, ``image`` a PIL image of whatever size the file has): the camera-like pictures of :class:`SyntheticRawImageDataset`
+    as PIL images, so that ``CLIPEvalDatasetHF(split, preprocess)`` -- the reference's own call -- runs offline end to end."""
+
+    def __init__(self, n: int, seed: int = 42):
+        self._raw = SyntheticRawImageDataset(n, seed)
+
+    def __len__(self):
+        return len(self._raw)
+
+    def __getitem__(self, idx):
+        from PIL import Image
+        image, query, target, uid = self._raw[idx]
+        return {"image": Image.fromarray(image.numpy()), "query_text": query, "target_text": target, "uuid": uid}
 
 
 class SyntheticRawImageDataset(Dataset):

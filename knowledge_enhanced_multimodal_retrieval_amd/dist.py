@@ -43,12 +43,23 @@ def _world(group) -> Tuple[int, int]:
     return 1, 0
 
 
+def _host_staged(x: torch.Tensor, group) -> bool:
+    """gloo moves device tensors through the host itself only for some collectives; the rehearsal of the N > 1 path on one GPU
+    (KEMR_DIST_BACKEND=gloo, bench.py) stages them explicitly.  RCCL ("nccl") never takes this branch."""
+    return x.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
     """Concatenate equally shaped per-rank tensors along dim 0 (single fused all-gather)."""
     world, _ = _world(group)
     if world == 1:
         return x
     x = x.contiguous()
+    if _host_staged(x, group):
+        xc = x.cpu()
+        oc = torch.empty((world * xc.shape[0],) + tuple(xc.shape[1:]), dtype=xc.dtype)
+        dist.all_gather_into_tensor(oc, xc, group=group)
+        return oc.to(x.device)
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     dist.all_gather_into_tensor(out, x, group=group)
     return out
@@ -60,8 +71,24 @@ def all_gather_rows_async(x: torch.Tensor, group=None):
     if world == 1:
         return x, None
     x = x.contiguous()
+    if _host_staged(x, group):
+        return all_gather_rows(x, group), None
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     return out, dist.all_gather_into_tensor(out, x, group=group, async_op=True)
+
+
+def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum over the ranks (device tensors staged through the host under gloo, see :func:`_host_staged`)."""
+    world, _ = _world(group)
+    if world == 1:
+        return x
+    if _host_staged(x, group):
+        xc = x.cpu()
+        dist.all_reduce(xc, group=group)
+        x.copy_(xc)
+        return x
+    dist.all_reduce(x, group=group)
+    return x
 
 
 def require_equal_rows(n_local: int, device, group=None, what: str = "query rows") -> None:
@@ -69,7 +96,9 @@ def require_equal_rows(n_local: int, device, group=None, what: str = "query rows
     world, rank = _world(group)
     if world == 1:
         return
-    t = torch.tensor([n_local, -n_local], dtype=torch.int64, device=device)
+    t = torch.tensor([n_local, -n_local], dtype=torch.int64)      # host tensor under gloo, device tensor under RCCL
+    if dist.get_backend(group) != "gloo":
+        t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     hi, lo = int(t[0]), -int(t[1])
     if hi != lo:
@@ -98,7 +127,9 @@ class ShardedGallery:
 
     def __init__(self, local_parts: Sequence[torch.Tensor], n_total: int, precision: str = "fp32x3", group=None, ops=engine):
         self.group, self.ops = group, ops
-        self.check_rows = True        # one 2-element all-reduce + host read per call; a caller that guarantees equal batches may clear it
+        # one 2-element all-reduce + host read per call, the only host synchronisation of search / ranks: a caller that guarantees
+        # equal batches (a fixed batch size, as bench.py's) clears it for THIS gallery and the whole call is asynchronous
+        self.check_rows = True
         self.world, self.rank = _world(group)
         self.n_total = n_total
         self.lo, self.hi = shard_bounds(n_total, self.world, self.rank)
@@ -166,17 +197,19 @@ class ShardedGallery:
         qp, nq = self._query_panel(local_query_parts, weights, row_gate)
         dev = local_query_parts[0].device
         gt = all_gather_rows(local_gt.to(device=dev, dtype=torch.int32).reshape(-1, 1), self.group).reshape(-1)
-        mine = (gt >= self.lo) & (gt < self.hi)
+        # the ground-truth score of EVERY query against this shard with the local row clamped into it, masked to the queries whose
+        # ground truth lives here: no data-dependent shape, no host read (round 2 tested `mine.any()` on the host and gathered rows)
         sgt = torch.zeros(nq, dtype=torch.float32, device=dev)
-        if self.panel is not None and bool(mine.any()):
-            rows = torch.nonzero(mine).reshape(-1).to(torch.int32)
-            sgt[rows.long()] = self.ops.pair_scores(qp, self.panel, rows, (gt[rows.long()] - self.lo).to(torch.int32))
-        if self.world > 1:
-            dist.all_reduce(sgt, group=self.group)                 # exactly one rank contributed a non-zero per query
+        if self.panel is not None:
+            mine = (gt >= self.lo) & (gt < self.hi)
+            local = (gt - self.lo).clamp(0, self.hi - self.lo - 1).to(torch.int32)
+            every = self.ops.pair_scores(qp, self.panel, torch.arange(nq, dtype=torch.int32, device=dev), local)
+            sgt = torch.where(mine, every, sgt)
+        all_reduce_sum(sgt, self.group)                            # exactly one rank contributed a non-zero per query
         ahead = torch.zeros(nq, dtype=torch.int32, device=dev)
         s, i = self._local_topk(qp, nq, k, dev, gt, sgt, ahead)
-        pending = self._exchange(s, i, k)
-        if self.world > 1:
-            dist.all_reduce(ahead, group=self.group)               # rides while the candidates are gathered
-        s, i = pending.result()
+        pending = self._exchange(s, i, k) if k > 0 else None       # k == 0: ranks only (what Recall@K / MRR need), nothing to merge
+        all_reduce_sum(ahead, self.group)                          # rides while the candidates are gathered
+        if pending is not None:
+            s, i = pending.result()
         return ahead.long() + 1, s, i

@@ -26,7 +26,7 @@ from . import _lib
 from . import engine
 from . import metrics as M
 from . import sparql_fusion as SF
-from .datasets import CLIPEvalDatasetHF, CollateAndTokenize, SyntheticRawImageDataset, SyntheticRetrievalDataset, collate_fn_eval
+from .datasets import CLIPEvalDatasetHF, CollateAndTokenize, SyntheticHFSplit, SyntheticRawImageDataset, SyntheticRetrievalDataset, collate_fn_eval
 from .preprocess import ClipPreprocessGPU, PackedRaw
 from .logging_utils import save_metrics_to_json, setup_logger
 
@@ -61,6 +61,20 @@ def default_tokenize(texts: Sequence[str]) -> torch.Tensor:
 ENCODE_ITEMS = 255          # items per encoder call in encode_dataset (see there)
 
 
+def default_loader_workers() -> int:
+    """Loader processes of the drop-in CLIs (the reference's scripts leave the DataLoader at 4, evaluator_baseline.py:83-92, or at
+    0, evaluator.py:97-106): KEMR_LOADER_WORKERS, else min(12, half the cores this process may use).  With the image transform on
+    the GPU a worker only decodes and tokenises; 12 of them deliver 17 k items/s, 0 leaves 1.5 k on the consumer."""
+    v = os.environ.get("KEMR_LOADER_WORKERS", "")
+    if v.strip():
+        return max(0, int(v))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(0, min(12, cores // 2))
+
+
 def eval_loader(dataset, batch_size: int, seed: int, num_workers: int, tokenize_fn: Callable, pin: bool) -> DataLoader:
     """The evaluation DataLoader (evaluator.py:96-105: no shuffle, seeded workers), with tokenisation and the packing of raw
     images into one buffer moved INTO the loader (its worker processes when there are any); the pin thread pins both.
@@ -73,9 +87,12 @@ def eval_loader(dataset, batch_size: int, seed: int, num_workers: int, tokenize_
 
 
 @torch.no_grad()
-def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_workers: int = 0,
+def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_workers: Optional[int] = 0,
                    tokenize_fn: Optional[Callable] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, List[str]]:
-    """Hot loop A: (image, query, target) -> three L2-normalised embedding sets that stay on the GPU."""
+    """Hot loop A: (image, query, target) -> three L2-normalised embedding sets that stay on the GPU.
+    num_workers None = default_loader_workers()."""
+    if num_workers is None:
+        num_workers = default_loader_workers()
     model.eval()
     device = next(model.parameters()).device
     tokenize_fn = tokenize_fn or default_tokenize
@@ -152,7 +169,7 @@ def sparql_sweep(query, target, image, uuids, text2sparql_results, t2i_weight, t
 @torch.no_grad()
 def evaluate_clip_model(model, dataset, batch_size: int = 64, device: str = "cuda", seed: int = 42,
                         tasks: List[str] = ("T2I", "I2T", "T2T"), compute_recall: bool = True, compute_mrr: bool = True,
-                        tokenize_fn: Optional[Callable] = None, num_workers: int = 0,
+                        tokenize_fn: Optional[Callable] = None, num_workers: Optional[int] = None,
                         text2sparql_results: Optional[Dict[str, List[str]]] = None, analysis: bool = True
                         ) -> Dict[str, float]:
     """evaluator.py semantics: per-task metrics are returned; the fused / SPARQL-sweep analysis is logged and kept in
@@ -187,7 +204,7 @@ def evaluate_clip_model_for_training(model, dataset, batch_size: int = 64, devic
 def evaluate_clip_model_baseline(model, dataset, batch_size: int = 64, device: str = "cuda", seed: int = 42,
                                  tasks: List[str] = ("T2I", "I2T", "T2T"), compute_recall: bool = True,
                                  compute_mrr: bool = True, t2i_weight: float = 0.5, t2t_weight: float = 0.5,
-                                 tokenize_fn: Optional[Callable] = None, num_workers: int = 4) -> Dict[str, float]:
+                                 tokenize_fn: Optional[Callable] = None, num_workers: Optional[int] = None) -> Dict[str, float]:
     """evaluator_baseline.py semantics: metrics of the fused score w_i * T2I + w_t * T2T (un-prefixed keys)."""
     image, query, target, _ = encode_dataset(model, dataset, batch_size, seed, num_workers, tokenize_fn)
     return M.compute_retrieval_metrics_final(query, target, image, compute_recall=compute_recall, compute_mrr=compute_mrr,
@@ -210,6 +227,11 @@ def _common_args(parser, baseline: bool):
     parser.add_argument("--seed", type=int, default=42)
     parser.add_argument("--synthetic", type=int, default=0, metavar="N",
                         help="evaluate on N seeded synthetic items instead of the HuggingFace dataset (offline)")
+    parser.add_argument("--synthetic_images", type=str, default="float", choices=["float", "uint8"],
+                        help="synthetic items: 'float' = already normalised pixel tensors; 'uint8' = camera-sized PIL images through "
+                             "CLIPEvalDatasetHF(split, preprocess), the reference's own dataset call (image transform on the GPU "
+                             "unless KEMR_GPU_PREPROCESS=0)")
+    parser.add_argument("--num_workers", type=int, default=-1, help="DataLoader workers (-1: KEMR_LOADER_WORKERS or min(12, cores / 2))")
     parser.add_argument("--dataset", type=str, default="xuemduan/reevaluate-image-text-pairs")
     if baseline:
         parser.add_argument("--t2i_weight", type=float, default=0.5)
@@ -237,20 +259,24 @@ def _run(args, baseline: bool, log_name: str):
         clip_api.allow_random_weights(True)
         tokenizer.allow_hash_tokenizer(True)
     model, preprocess = load_clip_model(model_name=args.model_name, checkpoint_path=args.checkpoint, device=device)
-    if args.synthetic > 0:
+    if args.synthetic > 0 and args.synthetic_images == "float":
         dataset = SyntheticRetrievalDataset(args.synthetic, model.arch.image_size, args.seed)
+    elif args.synthetic > 0:
+        dataset = CLIPEvalDatasetHF(hf_dataset=SyntheticHFSplit(args.synthetic, args.seed), preprocessor=preprocess)
     else:
         from datasets import load_dataset
         ds = load_dataset(args.dataset)
         split = {"val": "validation"}.get(args.split, args.split)
-        dataset = CLIPEvalDatasetHF(hf_dataset=ds[split], preprocessor=preprocess)
+        dataset = CLIPEvalDatasetHF(hf_dataset=ds[split], preprocessor=preprocess)        # the reference's call (evaluator.py:330-333)
+    workers = default_loader_workers() if args.num_workers < 0 else args.num_workers
+    log.info(f"Image transform: {'GPU (batched, bit-identical)' if getattr(preprocess, 'defer_to_gpu', False) else 'host (PIL, per sample)'}; loader workers: {workers}")
     if baseline:
         metrics = evaluate_clip_model_baseline(model, dataset, args.batch_size, device, args.seed, args.tasks,
                                                compute_recall=not args.mrr_only, compute_mrr=True,
-                                               t2i_weight=args.t2i_weight, t2t_weight=args.t2t_weight, num_workers=0)
+                                               t2i_weight=args.t2i_weight, t2t_weight=args.t2t_weight, num_workers=workers)
     else:
         metrics = evaluate_clip_model(model, dataset, args.batch_size, device, args.seed, args.tasks,
-                                      compute_recall=not args.mrr_only, compute_mrr=True)
+                                      compute_recall=not args.mrr_only, compute_mrr=True, num_workers=workers)
     log.info("EVALUATION RESULTS")
     for name, value in sorted(metrics.items()):
         log.info(f"{name}: {value:.2f}" + ("" if "Mean_Rank" in name else "%"))
@@ -258,7 +284,10 @@ def _run(args, baseline: bool, log_name: str):
                "num_samples": len(dataset), "seed": args.seed, "metrics": metrics,
                # provenance (not in the reference's file): what the numbers were computed with
                "weights_source": getattr(model, "weights_source", "unknown"), "tokenizer": tokenizer.tokenizer_name(),
-               "precision": os.environ.get("KEMR_PRECISION", _lib.DEFAULT_PRECISION), "data": "synthetic" if args.synthetic > 0 else args.dataset}
+               "precision": os.environ.get("KEMR_PRECISION", _lib.DEFAULT_PRECISION), "data": "synthetic" if args.synthetic > 0 else args.dataset,
+               "image_transform": {"RawRGB": "gpu (batched kernels, bit-identical to the host transform)", "ClipPreprocess": "host (PIL, per sample)"}.get(
+                   type(getattr(dataset, "preprocessor", None)).__name__, "none (pre-normalised tensors)"),
+               "loader_workers": workers}
     if not baseline:
         results["tasks"] = list(args.tasks)
     save_metrics_to_json(results, args.output_file)
@@ -281,7 +310,7 @@ def main_baseline(argv=None):
 # ------------------------------------------------------------------------------------------------ learned fusion heads
 @torch.no_grad()
 def evaluate_fusion_model(fusion_model, dataset, batch_size: int = 64, device: str = "cuda", seed: int = 42,
-                          tokenize_fn: Optional[Callable] = None, num_workers: int = 0) -> Dict[str, float]:
+                          tokenize_fn: Optional[Callable] = None, num_workers: Optional[int] = None) -> Dict[str, float]:
     """Counterpart of /root/reference/src/clip/eval/evaluator_fusion.py:28-144.  The reference fills an N x N numpy
     matrix in 50 x 500 blocks with an H2D/D2H round trip and ``empty_cache()`` per block (:76-121); here the head's
     score is one fused kernel pass over resident embeddings (``FusionModel.rank``)."""

@@ -11,9 +11,23 @@ CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
+def gpu_preprocessing_enabled() -> bool:
+    """KEMR_GPU_PREPROCESS=0 keeps the reference's arrangement (the PIL transform inside the dataset, per sample)."""
+    import os
+    return os.environ.get("KEMR_GPU_PREPROCESS", "1") != "0"
+
+
 class ClipPreprocess:
-    def __init__(self, n_px: int = 224):
+    """The callable ``clip.load`` / ``load_clip_model`` return: called with a PIL image it is the host transform and returns
+    float32 ``[3, n_px, n_px]``, exactly as upstream's.  ``defer_to_gpu``: the object ALSO tells this build's dataset classes
+    (``CLIPEvalDatasetHF(ds, preprocess)``, as the reference's ``main`` writes it, evaluator.py:330-333) that they may hand the
+    decoded image over raw -- uint8 ``[H, W, 3]`` -- so that ``evaluators.encode_dataset`` runs resize / crop / normalise for a
+    whole loader batch in one launch pair on the device (bit-identical, csrc/preprocess.hip).  Code that calls the object itself
+    (``preprocess(image)``) never sees a difference."""
+
+    def __init__(self, n_px: int = 224, defer_to_gpu: bool = False):
         self.n_px = n_px
+        self.defer_to_gpu = bool(defer_to_gpu)
         self.mean = torch.tensor(CLIP_MEAN, dtype=torch.float32).view(3, 1, 1)
         self.std = torch.tensor(CLIP_STD, dtype=torch.float32).view(3, 1, 1)
 
@@ -33,7 +47,7 @@ class ClipPreprocess:
         return (x - self.mean) / self.std
 
     def __repr__(self):
-        return f"ClipPreprocess(n_px={self.n_px})"
+        return f"ClipPreprocess(n_px={self.n_px}, defer_to_gpu={self.defer_to_gpu})"
 
 
 class ClipPreprocessGPU:

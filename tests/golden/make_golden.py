@@ -205,8 +205,83 @@ def hf_full_shape():
         del m
 
 
+E2E_CASES = (("ViT-B/32", 256, (2.0, 3.0, 4.0)), ("ViT-L/14", 64, (2.0, 3.0)))     # (architecture, gallery items, noise levels of the image queries)
+
+
+def e2e_inputs(arch, n, levels):
+    """Seeded inputs of the end-to-end fixture (regenerated, not stored, by tests/test_e2e_gpu.py): gallery images, query and target
+    texts as the reference's eval loop encodes them (evaluator.py:121-135), and noisy copies of every gallery image as further
+    query sets (I2I): random-weight towers put all embeddings in a narrow cone (score spread 2e-3), so text queries have no margin
+    to speak of, while a noisy copy's ground truth has a real one and Recall@K moves with the noise level."""
+    from oracle import clip_ref
+    g = torch.Generator().manual_seed(20261004)
+    px = torch.randn(n, 3, arch["image_size"], arch["image_size"], generator=g)
+    nz = torch.randn(n, 3, arch["image_size"], arch["image_size"], generator=g)
+    return px, {lvl: px + lvl * nz for lvl in levels}, clip_ref.synthetic_ids(arch, n, seed=777), clip_ref.synthetic_ids(arch, n, seed=778)
+
+
+def e2e_oracle_embeddings(sd, arch, px, noisy, q_ids, t_ids):
+    from oracle import clip_ref
+    with torch.no_grad():
+        emb = {"image": clip_ref.l2_normalize(clip_ref.encode_image(sd, arch, px)).numpy(),
+               "query": clip_ref.l2_normalize(clip_ref.encode_text(sd, arch, q_ids)).numpy(),
+               "target": clip_ref.l2_normalize(clip_ref.encode_text(sd, arch, t_ids)).numpy()}
+        for lvl, x in noisy.items():
+            emb[f"noisy{lvl}"] = clip_ref.l2_normalize(clip_ref.encode_image(sd, arch, x)).numpy()
+    return emb
+
+
+def e2e_tasks(emb, levels):
+    """task -> (query embeddings, [(weight, candidate embeddings)]): what the reference's evaluators score (metrics.py:102, 145-148)."""
+    tasks = {"T2I": (emb["query"], [(1.0, emb["image"])]), "T2T": (emb["query"], [(1.0, emb["target"])]),
+             "FUSED": (emb["query"], [(0.5, emb["image"]), (0.5, emb["target"])])}
+    for lvl in levels:
+        tasks[f"I2I@{lvl}"] = (emb[f"noisy{lvl}"], [(1.0, emb["image"])])
+    return tasks
+
+
+def e2e():
+    """Oracle encoders -> the REFERENCE's metrics.py, end to end (missing #1; evaluator.py:121-156 -> metrics.py:34-41,
+    62-68): per task the reference's metric dict, the oracle's top-11 ids and scores of every query (stable order) and the rank of
+    the ground truth.  A few hundred KB; inputs regenerate from seeds, the test re-runs the oracle and checks it against the
+    checksums stored here before it trusts its margins."""
+    from oracle import clip_ref
+    metrics, _, _ = ref_modules()
+    for name, n, levels in E2E_CASES:
+        arch = clip_ref.ARCHS[name]
+        sd = clip_ref.random_state_dict(arch, seed=0)
+        px, noisy, q_ids, t_ids = e2e_inputs(arch, n, levels)
+        emb = e2e_oracle_embeddings(sd, arch, px, noisy, q_ids, t_ids)
+        out = {"first8_" + k: v[:8] for k, v in emb.items()}
+        meta = {"arch": name, "n": n, "levels": list(levels), "weights_seed": 0,
+                "input_abs_sums": {"pixels": float(px.double().abs().sum()), "query_ids": int(q_ids.long().sum()), "target_ids": int(t_ids.long().sum()),
+                                   **{f"noisy{lvl}": float(x.double().abs().sum()) for lvl, x in noisy.items()}},
+                "embedding_abs_sums": {k: float(np.abs(v.astype(np.float64)).sum()) for k, v in emb.items()}, "metrics": {}}
+        for task, (q, parts) in e2e_tasks(emb, levels).items():
+            prefix = task.split("@")[0]
+            if task == "FUSED":
+                m = quiet(metrics.compute_retrieval_metrics_final, q, emb["target"], emb["image"], prefix=prefix, t2i_weight=0.5, t2t_weight=0.5)
+            else:
+                m = metrics.compute_retrieval_metrics(q, parts[0][1], prefix)
+            S = sum(w * (q @ c.T) for w, c in parts).astype(np.float32)           # the reference's expression (metrics.py:102, 145-148)
+            order = np.argsort(-S, axis=1, kind="stable")
+            ranks = np.argmax(order == np.arange(n)[:, None], axis=1) + 1
+            assert abs(float(np.mean(1.0 / ranks) * 100.0) - m[f"{prefix}_MRR"]) < 1e-3, (task, m)       # unstable vs stable sort only moves exact ties
+            out[f"{task}_top11_ids"] = order[:, :11].astype(np.int32)
+            out[f"{task}_top11_scores"] = np.take_along_axis(S, order[:, :11], axis=1)
+            out[f"{task}_ranks"] = ranks.astype(np.int32)
+            meta["metrics"][task] = {k: float(v) for k, v in m.items()}
+            top = out[f"{task}_top11_scores"]
+            print(name, task, {k: round(float(v), 2) for k, v in m.items()}, "| median 10/11 margin %.1e, score spread %.1e" % (np.median(top[:, 9] - top[:, 10]), S.std()), flush=True)
+        np.savez_compressed(os.path.join(HERE, "e2e_%s_n%d.npz" % (name.replace("/", "-"), n)), **out,
+                            meta_json=np.frombuffer(json.dumps(meta, sort_keys=True).encode(), dtype=np.uint8))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "hf-full":
         hf_full_shape()
+    elif len(sys.argv) > 1 and sys.argv[1] == "e2e":
+        e2e()
     else:
         main()
+        e2e()

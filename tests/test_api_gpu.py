@@ -63,10 +63,10 @@ def test_config0_vit_b32_zeroshot_256(device, tmp_path):
     assert sum(abs(res["metrics"][k] - exact[k]) > 1e-9 for k in exact) <= 4
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp8", "fp8-mlp"])
+@pytest.mark.parametrize("precision", ["bf16-res16", "fp8", "fp8-mlp"])
 def test_precision_switch_reaches_the_drop_in_modules(device, tmp_path, monkeypatch, precision):
     """KEMR_PRECISION selects the encoder precision behind the unchanged CLI: the evaluator runs and its
-    embeddings differ from the default (bf16 operands, bf16 residual stream) run by what that precision costs, no more."""
+    embeddings differ from the default (bf16 operands, fp32 residual stream) run by what that precision costs, no more."""
     import clip
     from knowledge_enhanced_multimodal_retrieval_amd import datasets, evaluators
     ds = datasets.SyntheticRetrievalDataset(64, 224, seed=7)
@@ -74,15 +74,50 @@ def test_precision_switch_reaches_the_drop_in_modules(device, tmp_path, monkeypa
         warnings.simplefilter("ignore")
         monkeypatch.delenv("KEMR_PRECISION", raising=False)
         base, _ = clip.load("ViT-B/32", device="cuda")
-        assert base.engine().precision == "bf16-res16"
+        assert base.engine().precision == "bf16"
         ref_img, ref_qry, _, _ = evaluators.encode_dataset(base, ds, 32, 7)
         monkeypatch.setenv("KEMR_PRECISION", precision)
         model, _ = clip.load("ViT-B/32", device="cuda")
         assert model.engine().precision == precision
         img, qry, _, _ = evaluators.encode_dataset(model, ds, 32, 7)
-    tol = {"bf16": 1e-3, "fp8": 5e-3, "fp8-mlp": 2e-2}[precision]
+    tol = {"bf16-res16": 1e-3, "fp8": 5e-3, "fp8-mlp": 2e-2}[precision]
     di, dq = float((1 - _cos(img, ref_img)).max()), float((1 - _cos(qry, ref_qry)).max())
     assert 0 < di < tol and 0 < dq < tol
+
+
+def test_cli_runs_the_batched_device_pipeline_behind_the_reference_dataset_call(device, tmp_path, monkeypatch):
+    """`python -m src.clip.eval.evaluator` on camera-sized uint8 sources.  The CLI builds its dataset exactly as the
+    reference's main does -- CLIPEvalDatasetHF(split, preprocess) with the object load_clip_model returned (evaluator.py:330-333) --
+    and by default that object defers the image transform to the GPU (one launch pair per loader batch, loader workers on):
+    the metrics, and the embeddings behind them, are IDENTICAL to the run with the host transform (KEMR_GPU_PREPROCESS=0)."""
+    from src.clip.eval.evaluator import main
+    from knowledge_enhanced_multimodal_retrieval_amd import clip_api, datasets, evaluators, tokenizer
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("KEMR_GPU_PREPROCESS", mode)
+        out = tmp_path / f"uint8_{mode}.json"
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = main(["--model_name", "ViT-B/32", "--batch_size", "24", "--device", "cuda", "--synthetic", "72", "--synthetic_images", "uint8",
+                        "--output_file", str(out)] + (["--num_workers", "0"] if mode == "0" else []))
+        saved = json.loads(out.read_text())
+        assert saved["image_transform"].startswith("gpu" if mode == "1" else "host"), saved["image_transform"]
+        assert saved["num_samples"] == 72 and (saved["loader_workers"] == evaluators.default_loader_workers() if mode == "1" else saved["loader_workers"] == 0)
+        runs[mode] = res["metrics"]
+    assert runs["1"] == runs["0"], (runs["1"], runs["0"])                              # bit-identical pixels in, same kernels: equal, not close
+    # the embeddings themselves, through the function API with the two preprocess objects
+    monkeypatch.setenv("KEMR_GPU_PREPROCESS", "1")
+    clip_api.allow_random_weights(True)
+    tokenizer.allow_hash_tokenizer(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model, pre = clip_api.load("ViT-B/32", device="cuda")
+    assert pre.defer_to_gpu and tuple(pre(__import__("PIL.Image").Image.new("RGB", (300, 200))).shape) == (3, 224, 224)      # still the host transform when called
+    split = datasets.SyntheticHFSplit(40, 3)
+    gpu = evaluators.encode_dataset(model, datasets.CLIPEvalDatasetHF(split, pre), 16, 3, 2)
+    from knowledge_enhanced_multimodal_retrieval_amd.preprocess import ClipPreprocess
+    host = evaluators.encode_dataset(model, datasets.CLIPEvalDatasetHF(split, ClipPreprocess(224)), 16, 3, 0)
+    assert torch.equal(gpu[0], host[0]) and torch.equal(gpu[1], host[1]) and gpu[3] == host[3]
 
 
 def test_config2_fused_scoring_cli(device, tmp_path):
@@ -135,17 +170,48 @@ def test_evaluate_fusion_model_end_to_end(device, tmp_path, ft):
     image, query, target, _ = encode_dataset(cm, ds, 32, 42, 0, None)
     S = fm(query, image, target).double().cpu().numpy()
     want = metrics_ref.retrieval_metrics_from_similarity(S)
+    # ALWAYS asserted: a query is ambiguous only if another candidate scores within 1e-5 of its ground truth
+    # (the head's fp32 scores against this fp64 re-ranking); at most two of the 80 may be, each can move one Recall@K by 100 / 80
+    # points and Mean_Rank by its number of near-ties / 80 -- with none ambiguous the metrics are EQUAL
     d = np.abs(S - np.diag(S)[:, None])
     np.fill_diagonal(d, np.inf)
-    if d.min() > 1e-5:                       # no near-tie between a ground truth and another candidate: ranks are unambiguous
-        for key in ("R@1", "R@5", "R@10", "R@20", "MRR", "Mean_Rank"):
-            assert res2[key] == pytest.approx(want[key], abs=1e-9), key
+    amb = int((d.min(axis=1) <= 1e-5).sum())
+    near = int((d <= 1e-5).sum())
+    assert amb <= 2, amb
+    for key in ("R@1", "R@5", "R@10", "R@20"):
+        assert abs(res2[key] - want[key]) <= 100.0 * amb / 80 + 1e-9, (key, res2[key], want[key], amb)
+    assert abs(res2["Mean_Rank"] - want["Mean_Rank"]) <= near / 80 + 1e-9 and abs(res2["MRR"] - want["MRR"]) <= 100.0 * amb / 80 + 1e-9
     assert 1.0 <= res2["Mean_Rank"] <= 80.0
 
 
+def test_writes_through_dot_data_need_refresh_or_the_digest(device, monkeypatch):
+    """`p.data.copy_()` / `p.data.mul_()` do not bump the parameter's version counter, so the cheap fingerprint cannot
+    see them.  Documented behaviour: stale until `refresh()`; with KEMR_WEIGHT_DIGEST=1 the content digest catches them."""
+    from knowledge_enhanced_multimodal_retrieval_amd import clip_api
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model, _ = clip_api.load("ViT-B/32", device="cuda")
+    px = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(1)).cuda()
+    monkeypatch.delenv("KEMR_WEIGHT_DIGEST", raising=False)
+    a = model.encode_image(px).clone()
+    v0 = model.visual.proj._version
+    model.visual.proj.data.mul_(2.0)
+    assert model.visual.proj._version == v0                          # the blind spot itself
+    assert torch.equal(model.encode_image(px), a)                    # stale packed weights, as documented ...
+    model.refresh()
+    b = model.encode_image(px)
+    assert torch.allclose(b, 2.0 * a, rtol=2e-2, atol=1e-3)          # ... until refresh()
+    monkeypatch.setenv("KEMR_WEIGHT_DIGEST", "1")
+    model.encode_image(px)                                           # first call with the digest: re-packs once (fingerprint changed shape)
+    model.visual.proj.data.copy_(model.visual.proj.data * 0.5)
+    c = model.encode_image(px)
+    assert torch.allclose(c, a, rtol=2e-2, atol=1e-3) and not torch.allclose(c, b)
+
+
 def test_module_repacks_after_in_place_weight_edits_and_refuses_nan(device):
-    """(a) the packed engine copy follows in-place parameter edits (optimizer.step(), p.data.copy_) without a manual
-    refresh(), and a deepcopy never shares the raw library handle; (b) non-finite scores are refused instead of ranking first."""
+    """(a) the packed engine copy follows in-place parameter edits that autograd's version counters see
+    (optimizer.step(), p.mul_() under no_grad) without a manual refresh(), and a deepcopy never shares the raw library
+    handle; (b) non-finite scores are refused instead of ranking first.  (Writes through p.data: the test above.)"""
     import copy
     from knowledge_enhanced_multimodal_retrieval_amd import clip_api, ranking
     with warnings.catch_warnings():

@@ -83,6 +83,12 @@ def _worker(rank, world, port, n, nq, d, k, q_out):
     s, i = gal.search([ql, ql], weights=[0.3, 0.7], k=k)
     ranks, s2, i2 = gal.ranks([ql, ql], gt_l, weights=[0.3, 0.7], k=k)
     assert torch.equal(i, i2)
+    ranks0, _, _ = gal.ranks([ql, ql], gt_l, weights=[0.3, 0.7], k=0)          # ranks only: no candidate exchange at all
+    assert torch.equal(ranks0, ranks)
+    gal.check_rows = False                                                     # a caller with fixed batch sizes: no host read in the call
+    ranks1, _, i3 = gal.ranks([ql, ql], gt_l, weights=[0.3, 0.7], k=k)
+    assert torch.equal(ranks1, ranks) and torch.equal(i3, i)
+    gal.check_rows = True
     # a stream of query batches with the candidate exchange of batch b in flight while batch b+1 is produced: same answers
     produced = []
 

@@ -197,19 +197,31 @@ def test_residual_fusion_switch(device, precision):
     assert float((1 - _cos(outs[True][0], outs[False][0])).max()) < close and float((1 - _cos(outs[True][1], outs[False][1])).max()) < close
 
 
-def test_fp8_recall_at_10_within_0p2_percent_of_bf16(device):
-    """Retrieval with a noisy copy of every gallery image as the query, at three noise levels (bf16 Recall@10 about 99.8 /
-    88 / 58 %): the "fp8" engine's Recall@10 must stay within 0.2 percentage points of the bf16 engine's on the same inputs
-    (BASELINE config 5's bar).  "fp8-mlp" meets that only where recall is saturated; its loss is bounded and recorded.
-    N = 16 384 items: 0.2 points are 33 queries (at 4 096 a change of the GEMM's rounding order alone moved bf16's own
-    Recall@10 by 0.14 points between rounds 1 and 2)."""
-    from knowledge_enhanced_multimodal_retrieval_amd import metrics
-    name, n, chunk = "ViT-B/32", 16384, 1024
+RECALL_BAR = 0.2        # percentage points of Recall@10 (BASELINE.json configs[4]); FIXED -- a mode that misses it is opt-in, not a wider bar
+
+
+def test_recall_at_10_default_against_oracle_and_fp8_within_0p2(device):
+    """Retrieval with a noisy copy of every gallery image as the query, at three noise levels (Recall@10 about 99 / 77 / 42 %).
+    (1) The DEFAULT precision is anchored to the ORACLE: on the first 512 gallery items and their queries the fp32 CPU oracle
+        encodes the same pixels; the default engine's ground-truth ranks may differ from the oracle's only where the oracle itself
+        scores a competitor within 2e-4 of the ground truth, and its Recall@10 on that subset is the oracle's within those queries.
+    (2) BASELINE config 5's bar, fixed at 0.2 points: the "fp8" engine's Recall@10 over all N = 16 384 items stays within 0.2 points
+        of the default engine's at every level (0.2 points are 33 queries; at 4 096 items a change of the GEMM's rounding order
+        alone moved Recall@10 by 0.14 points between rounds 1 and 2).
+    (3) The other modes are RECORDS, printed with inside_bar true / false and not asserted: "bf16-res16" / "fp8-res16" (bf16
+        residual stream: 0.3-0.7 points where recall is noise-limited) and "fp8-mlp" (about one point) are opt-in because they
+        miss the bar; round 2 widened it four times to keep them green as defaults, which is what this test no longer does."""
+    from knowledge_enhanced_multimodal_retrieval_amd import _lib, metrics
+    from oracle import metrics_ref
+    name, n, chunk, n_sub = "ViT-B/32", 16384, 1024, 512
     arch = ARCHS[name]
-    sd = clip_ref.random_state_dict(clip_ref.ARCHS[name], seed=0)
+    oa = clip_ref.ARCHS[name]
+    sd = clip_ref.random_state_dict(oa, seed=0)
     levels = (1.5, 2.0, 2.5)
-    res = {}
-    precs = ("bf16", "bf16-res16", "fp8", "fp8-res16", "fp8-mlp")
+    default = _lib.DEFAULT_PRECISION
+    assert default == "bf16", "the default precision must be the one that meets the bar (fp32 residual stream)"
+    res, emb_default = {}, {}
+    precs = (default, "fp8", "bf16-res16", "fp8-res16", "fp8-mlp")
     for prec in precs:
         eng = engine.ClipEngine(arch, device, precision=prec)
         eng.load_state_dict(sd)
@@ -221,22 +233,43 @@ def test_fp8_recall_at_10_within_0p2_percent_of_bf16(device):
             gal.append(eng.encode_image(base, normalize=True))
             for lvl in levels:
                 qry[lvl].append(eng.encode_image(base + lvl * noise, normalize=True))
-        gal = torch.cat(gal).cpu().numpy()
+        gal = torch.cat(gal)
         for lvl in levels:
-            res[(prec, lvl)] = metrics.compute_retrieval_metrics(torch.cat(qry[lvl]).cpu().numpy(), gal, "T2I")
+            q = torch.cat(qry[lvl])
+            res[(prec, lvl)] = metrics.compute_retrieval_metrics(q, gal, "T2I")
+            if prec == default:
+                emb_default[lvl] = (q[:n_sub].cpu().numpy(), gal[:n_sub].cpu().numpy())
+        del eng
     for lvl in levels:
         print(lvl, {k: tuple(round(res[(p, lvl)][k], 2) for p in precs) for k in ("T2I_R@1", "T2I_R@10", "T2I_MRR")})
+    # ---- (1) the default engine against the oracle on the first n_sub items (the same pixels, regenerated on the host)
+    g = torch.Generator(device=device).manual_seed(1000)
+    base = torch.randn(chunk, 3, 224, 224, generator=g, device=device)
+    noise = torch.randn(chunk, 3, 224, 224, generator=g, device=device)
+    base, noise = base[:n_sub].cpu(), noise[:n_sub].cpu()
+    with torch.no_grad():
+        o_gal = clip_ref.l2_normalize(clip_ref.encode_image(sd, oa, base)).numpy()
     for lvl in levels:
-        ref = res[("bf16", lvl)]["T2I_R@10"]
-        assert abs(ref - res[("fp8", lvl)]["T2I_R@10"]) <= 0.2 + 1e-9
-        # The bf16 residual stream (the default engine; 1 - cos 4e-5 against the oracle where "bf16" has 3e-6) is not free on
-        # this set: random-weight towers put all embeddings within a narrow cone, so where recall is noise-limited (the two
-        # upper levels) its 48 extra roundings per item cost 0.14 / 0.35 points (measured, round 2); "fp8-res16" 0.36 / 0.28.
-        # Inside config 5's bar only where recall is saturated; bounded and recorded elsewhere, like "fp8-mlp".
-        # (records, not bars: two builds of this round measured 0.14 / 0.35 and 0.31 / 0.27 for bf16-res16, 0.36 / 0.28 and
-        # 0.42 / 0.23 for fp8-res16 -- a change of the softmax summation order moves them by 0.1)
-        # With the residual add inside the out-proj / fc2 epilogues (the default since the end of round 2: x rounded twice per
-        # layer) the records are 0.58 / 0.46 (bf16-res16) and 0.73 / 0.49 (fp8-res16); KEMR_RESADD=0 gives the figures above.
-        assert abs(ref - res[("bf16-res16", lvl)]["T2I_R@10"]) <= (0.2 if lvl == 1.5 else 1.0) + 1e-9
-        assert abs(ref - res[("fp8-res16", lvl)]["T2I_R@10"]) <= (0.2 if lvl == 1.5 else 1.0) + 1e-9
-        assert abs(ref - res[("fp8-mlp", lvl)]["T2I_R@10"]) <= (0.3 if lvl == 1.5 else 2.0) + 1e-9      # 0.19 / 0.21 at the saturated level: at the bar, not inside it
+        with torch.no_grad():
+            o_q = clip_ref.l2_normalize(clip_ref.encode_image(sd, oa, base + lvl * noise)).numpy()
+        S = metrics_ref.similarity(o_q, o_gal)
+        o_ranks = metrics_ref.ranks_by_count(S.astype(np.float64))
+        hq, hg = emb_default[lvl]
+        assert float((1 - (hq * o_q).sum(1)).max()) < COS_TOL and float((1 - (hg * o_gal).sum(1)).max()) < COS_TOL
+        h_ranks = metrics_ref.ranks_by_count(metrics_ref.similarity(hq, hg).astype(np.float64))
+        sgt = S[np.arange(n_sub), np.arange(n_sub)]
+        near = (np.abs(S - sgt[:, None]) <= 2e-4).sum(axis=1) - 1
+        moved = np.abs(h_ranks - o_ranks)
+        r10_o, r10_h = 100.0 * np.mean(o_ranks <= 10), 100.0 * np.mean(h_ranks <= 10)
+        may_cross = ((o_ranks - near <= 10) & (o_ranks > 10)) | ((o_ranks + near > 10) & (o_ranks <= 10))
+        print(f"level {lvl}, first {n_sub} items: Recall@10 oracle {r10_o:.2f} / default engine {r10_h:.2f}; ranks identical "
+              f"{int((moved == 0).sum())}/{n_sub}, beyond the oracle's own 2e-4 neighbourhood: {int((moved > near).sum())}")
+        assert int((moved > near).sum()) <= n_sub // 100, (lvl, int((moved > near).sum()))
+        assert abs(r10_h - r10_o) <= 100.0 * may_cross.sum() / n_sub + 1e-9 and abs(r10_h - r10_o) <= 2 * RECALL_BAR + 1e-9, (lvl, r10_h, r10_o)
+    # ---- (2) config 5's bar for the fp8 encoders, (3) records for the opt-in modes
+    for lvl in levels:
+        ref = res[(default, lvl)]["T2I_R@10"]
+        rec = {p: {"R@10": round(res[(p, lvl)]["T2I_R@10"], 3), "delta": round(res[(p, lvl)]["T2I_R@10"] - ref, 3),
+                   "inside_bar": bool(abs(res[(p, lvl)]["T2I_R@10"] - ref) <= RECALL_BAR + 1e-9)} for p in precs[1:]}
+        print(f"level {lvl}: default R@10 {ref:.3f};", rec)
+        assert rec["fp8"]["inside_bar"], (lvl, rec["fp8"])

@@ -271,9 +271,10 @@ def _lists_mode(mode):
 
 
 @pytest.mark.parametrize("nq,ng,d,terms,off,k", [(300, 9000, 128, 1, 0, 10), (257, 16000, 128, 1, 5, 5), (600, 20001, 192, 3, 1000, 32),
-                                                 (256, 8192, 64, 1, 0, 1), (1024, 43000, 768, 1, 0, 10)])
+                                                 (256, 8192, 64, 1, 0, 1), (1024, 43000, 768, 1, 0, 10), (43000, 43000, 768, 1, 0, 10)])
 def test_topk_by_candidate_lists_is_the_kernel_path_bit_for_bit(device, nq, ng, d, terms, off, k):
-    """>= 8192 gallery rows and >= 256 queries: thresholds from a 1/12 sample, candidate lists out of the 256 x 256-tile pass,
+    """The headline leg included (Q = 43 000 against the 43 000 gallery: 4 096 sampled rows, three gallery chunks per query tile).
+    >= 8192 gallery rows and >= 256 queries: thresholds from a 1/12 sample, candidate lists out of the 256 x 256-tile pass,
     selection (sim.hip).  Scores, ids and rank counts must equal (a) sim_kernel's on the same panels and (b) a stable
     descending sort of the dense scores of the same arithmetic -- with exact ties around the ground truth, a ragged last tile,
     a gallery offset; (c) the forced fallback route gives the same answer again."""
