@@ -176,7 +176,7 @@ def main():
     if args.resadd >= 0:
         eng.set_residual_fusion(bool(args.resadd))
     # residual add inside the out-proj / fc2 epilogues: the library's default (KEMR_RESADD=0 turns it off)
-    resadd_on = eng.residual_fusion()
+    resadd_on = eng.residual_fusion_active()
     eng.load_state_dict(random_weights(arch, seed=0))
 
     g = torch.Generator().manual_seed(1234 + rank)
@@ -274,6 +274,99 @@ def main():
         "encode_frac_of_bf16_peak": flops_item_step * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS,
     }
 
+    def pipeline_leg():
+        # ------------------------------------------------------------------ the same encode through the host input pipeline
+        # camera-sized uint8 sources -> CLIPEvalDatasetHF(split, preprocess), the reference's own dataset call
+        # (evaluator.py:330-333), with the preprocess object clip.load returns -> DataLoader workers (decode stand-in, tokenise, pack) ->
+        # one pinned H2D copy + one preprocess launch pair per loader batch -> the three encoders (evaluators.encode_dataset, what the
+        # drop-in CLIs run).  PCIe-inclusive by construction; worker start-up is inside the timed region.  N = 1 only.
+        if world == 1 and not args.no_pipeline and args.model == "ViT-L/14":
+            import warnings
+            from knowledge_enhanced_multimodal_retrieval_amd import clip_api, datasets as kds, evaluators, tokenizer
+            clip_api.allow_random_weights(True)
+            tokenizer.allow_hash_tokenizer(True)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                pm, ppre = clip_api.load(args.model, device=str(dev))
+            n_pipe, workers = args.pipeline_items, evaluators.default_loader_workers()
+            split = kds.SyntheticHFSplit(n_pipe, 11)
+            evaluators.encode_dataset(pm, kds.CLIPEvalDatasetHF(kds.SyntheticHFSplit(510, 12), ppre), 64, 1, 0)      # warm: kernels, workspaces
+            barrier()
+            t1 = time.perf_counter()                                       # the host side alone (loader processes, pin thread): its ceiling
+            n_l = sum(len(b[3]) for b in evaluators.eval_loader(kds.CLIPEvalDatasetHF(kds.SyntheticHFSplit(n_pipe // 2, 13), ppre), 64, 1, workers,
+                                                                evaluators.default_tokenize, True))
+            loader_only = 3 * n_l / (time.perf_counter() - t1)
+            spent = {}
+            if os.environ.get("KEMR_BENCH_TRACE"):                         # host seconds inside the consumer's calls (diagnostic)
+                # device time of the consumer's three kinds of call in THIS process, each synchronised
+                from knowledge_enhanced_multimodal_retrieval_amd.preprocess import ClipPreprocessGPU, pack_raw
+                raw = kds.SyntheticRawImageDataset(64, 5)
+                packed = pack_raw([raw[i][0] for i in range(64)]).pin_memory()
+                gp_ = ClipPreprocessGPU(224, dev)
+                gp_.batch(packed); torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                for _ in range(10):
+                    gp_.batch(packed)
+                torch.cuda.synchronize()
+                spent["sync.preprocess_batch_ms"] = (time.perf_counter() - t_) * 100
+                xi = torch.randn(255, 3, 224, 224, device=dev)
+                pm.encode_image(xi, normalize=True); torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                for _ in range(4):
+                    pm.encode_image(xi, normalize=True)
+                torch.cuda.synchronize()
+                spent["sync.encode_image_255_ms"] = (time.perf_counter() - t_) * 250
+                t_ = time.perf_counter()
+                for _ in range(4):
+                    eng.encode_image(xi, normalize=True)
+                torch.cuda.synchronize()
+                spent["sync.main_engine_encode_image_255_ms"] = (time.perf_counter() - t_) * 250
+                def timed(owner, name, key):
+                    fn = getattr(owner, name)
+
+                    def wrapper(*a, **k):
+                        t = time.perf_counter()
+                        try:
+                            return fn(*a, **k)
+                        finally:
+                            spent[key] = spent.get(key, 0.0) + time.perf_counter() - t
+                            spent[key + ".calls"] = spent.get(key + ".calls", 0) + 1
+                    setattr(owner, name, wrapper)
+                import faulthandler
+                faulthandler.dump_traceback_later(8, repeat=False, file=sys.stderr)      # where the consumer sits 8 s into the run
+                _to = torch.Tensor.to
+
+                def to_timed(self_, *a, **k):
+                    t = time.perf_counter()
+                    try:
+                        return _to(self_, *a, **k)
+                    finally:
+                        if self_.dtype == torch.uint8 and self_.dim() == 1:
+                            spent["uint8 .to(device)"] = spent.get("uint8 .to(device)", 0.0) + time.perf_counter() - t
+                            spent["uint8 pinned"] = spent.get("uint8 pinned", 0) + int(self_.is_pinned())
+                torch.Tensor.to = to_timed
+                timed(_lib.lib(), "kemr_preprocess_u8_batch", "C kemr_preprocess_u8_batch")
+                timed(evaluators.ClipPreprocessGPU, "batch", "preprocess.batch")
+                timed(pm, "encode_image", "encode_image")
+                timed(pm, "encode_text", "encode_text")
+                timed(pm, "engine", "engine()")
+                timed(pm._engine.__class__, "load_state_dict", "engine.load_state_dict")
+            t1 = time.perf_counter()
+            pi, pq, pt, pids = evaluators.encode_dataset(pm, kds.CLIPEvalDatasetHF(split, ppre), 64, 1, workers)
+            barrier()
+            dtp = time.perf_counter() - t1
+            assert pi.shape[0] == n_pipe and len(pids) == n_pipe and bool(torch.isfinite(pi).all())
+            result["pipeline"] = {"items_per_s": 3 * n_pipe / dtp, "images_per_s": n_pipe / dtp, "seconds": dtp, "items": n_pipe,
+                                  "loader_workers": workers, "loader_batch": 64, "host_cores": os.cpu_count(), "loader_only_items_per_s": loader_only, **({"host_seconds": spent} if spent else {}),
+                                  "image_transform": "gpu" if ppre.defer_to_gpu else "host",
+                                  "source": "uint8 PIL images of 8 camera-like sizes (224x224 .. 600x800) -> CLIPEvalDatasetHF(split, preprocess) -> "
+                                            "evaluators.encode_dataset; worker start-up and PCIe included"}
+            del pm, pi, pq, pt
+
+    if os.environ.get("KEMR_BENCH_PIPELINE_FIRST"):
+        pipeline_leg()
+        args.no_pipeline = True
+
     # ------------------------------------------------------------------ roofline: per-class hipEvent timing
     L = _lib.lib()
     prof_steps = 10                                  # whole text groups only inside the profiled region; the rest drains after it
@@ -317,34 +410,7 @@ def main():
     result["kernel_ms_per_step"] = {"gemm": ms[0], "layernorm": ms[1], "attention": ms[2], "embed_tail": ms[3]}
     result["config"]["residual_add_in_gemm_epilogue"] = resadd_on
 
-    # ------------------------------------------------------------------ the same encode through the host input pipeline
-    # camera-sized uint8 sources -> CLIPEvalDatasetHF(split, preprocess), the reference's own dataset call
-    # (evaluator.py:330-333), with the preprocess object clip.load returns -> DataLoader workers (decode stand-in, tokenise, pack) ->
-    # one pinned H2D copy + one preprocess launch pair per loader batch -> the three encoders (evaluators.encode_dataset, what the
-    # drop-in CLIs run).  PCIe-inclusive by construction; worker start-up is inside the timed region.  N = 1 only.
-    if world == 1 and not args.no_pipeline and args.model == "ViT-L/14":
-        import warnings
-        from knowledge_enhanced_multimodal_retrieval_amd import clip_api, datasets as kds, evaluators, tokenizer
-        clip_api.allow_random_weights(True)
-        tokenizer.allow_hash_tokenizer(True)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            pm, ppre = clip_api.load(args.model, device=str(dev))
-        n_pipe, workers = args.pipeline_items, evaluators.default_loader_workers()
-        split = kds.SyntheticHFSplit(n_pipe, 11)
-        evaluators.encode_dataset(pm, kds.CLIPEvalDatasetHF(kds.SyntheticHFSplit(510, 12), ppre), 64, 1, 0)      # warm: kernels, workspaces
-        barrier()
-        t1 = time.perf_counter()
-        pi, pq, pt, pids = evaluators.encode_dataset(pm, kds.CLIPEvalDatasetHF(split, ppre), 64, 1, workers)
-        barrier()
-        dtp = time.perf_counter() - t1
-        assert pi.shape[0] == n_pipe and len(pids) == n_pipe and bool(torch.isfinite(pi).all())
-        result["pipeline"] = {"items_per_s": 3 * n_pipe / dtp, "images_per_s": n_pipe / dtp, "seconds": dtp, "items": n_pipe,
-                              "loader_workers": workers, "loader_batch": 64, "host_cores": os.cpu_count(),
-                              "image_transform": "gpu" if ppre.defer_to_gpu else "host",
-                              "source": "uint8 PIL images of 8 camera-like sizes (224x224 .. 600x800) -> CLIPEvalDatasetHF(split, preprocess) -> "
-                                        "evaluators.encode_dataset; worker start-up and PCIe included"}
-        del pm, pi, pq, pt
+    pipeline_leg()
 
     # ------------------------------------------------------------------ similarity + top-10 on the 43k gallery
     if not args.no_sim:
@@ -415,7 +481,7 @@ def main():
             e2 = engine.ClipEngine(arch, dev, precision=prec)
             e2.load_state_dict(random_weights(arch, seed=0))
 
-            s2 = Stepper(e2, e2.residual_fusion())
+            s2 = Stepper(e2, e2.residual_fusion_active())
             for _ in range(3):
                 s2.step()
             s2.drain()

@@ -24,7 +24,8 @@ extern "C" {
  *   "gemm_order"    tile order of the persistent GEMM: 0 = N fastest, else log2(column-group width) + 1 (default 3)
  *   "gemm_conc"     both wave halves' epilogues in one barrier interval: 0 never, 1 always, 2 = QuickGELU epilogue only (default)
  *   "gemm_kl"       K loop of the persistent GEMM: 0 = eight 256-cycle barrier intervals per K-tile (default), 1 = four of 512
- *   "attn_waves"    waves per attention workgroup at T = 257: 0 = default (4), 6
+ *   "attn_v"        attention kernel at T = 257: 0 = the 16-query-tile kernel (default), 1 = 32-query tiles on v_mfma_f32_32x32x16_bf16
+ *   "attn_waves"    waves per workgroup of the 16-query-tile kernel at T = 257: 0 = default (4), 6
  *   "sim_lists"     kemr_sim_topk: 0 = never the candidate-list route, 1 = where it applies (default), 2 = lists, then the
  *                   exact fallback forced */
 int kemr_debug_set(const char* key, int value);

@@ -66,8 +66,13 @@ def _weights_for(name: str):
     return None
 
 
-def load(name: str, device: Union[str, torch.device] = "cuda" if torch.cuda.is_available() else "cpu",
+def load(name: str, device: Union[str, torch.device, None] = None,
          jit: bool = False, download_root: str = None) -> Tuple[CLIP, ClipPreprocess]:
+    """device None = "cuda" when a GPU is visible, else "cpu" (upstream's default), decided at CALL time: evaluating
+    torch.cuda.is_available() in the signature initialised the HIP runtime in every process that merely imported this module --
+    the loader processes included (round 3: 13 processes with the GPU open)."""
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
     if jit:
         raise RuntimeError("clip.load(jit=True) is not supported by the HIP engine")
     path = None

@@ -212,6 +212,193 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
     }
 }
 
+// ---- T = 257 (ViT-L/14 and ViT-B/16 vision towers): 32-query tiles on v_mfma_f32_32x32x16_bf16 (round 3) ---------------------------
+// Round 2's PMC pass of the 16-query kernel above put a wave at one third issuing, one third parked at s_waitcnt and one third
+// issue-stalled, MFMA pipe 20 % busy: per 16 queries it issues 72 MFMAs, 36 + 72 LDS reads and ~1 100 cycles of softmax VALU, with
+// every phase waiting on the one before.  A 32 x 32 tile halves the MFMA and LDS-read instructions per query (one K / V fragment
+// serves 32 queries), an MFMA holds the issue port for 8 of its 32 cycles instead of 8 of 16, and 257 queries are 8 full tiles --
+// two per wave, balanced -- plus ONE query (the 16-query kernel: 17 tiles as 5 / 4 / 4 / 4).
+//   S^T block (32 keys x 32 queries) = K_blk . Q^T: A = K rows (ds_read_b128: lane (key l & 31, half l >> 5) holds d = 16 ks + 8 half
+//   .. + 7), B = Q rows straight from HBM in the same shape; a lane ends with 16 keys of ONE query per block (C layout: key =
+//   (reg & 3) + 8 (reg >> 2) + 4 half), so row max / sum are the in-lane reduction and one exchange with lane ^ 32.
+//   O^T (64 x 32) += V^T . P^T per 16-key step: the score registers 8 st .. 8 st + 7, packed to bf16, ARE the B fragment (k slot
+//   8 half + j <-> key 16 st + 8 (j >> 2) + 4 half + (j & 3)); the A fragment takes the same keys from the row-major V image with two
+//   ds_read_b64_tr_b16 (rows 16 st + 4 half + 0..3 and + 8).
+// LDS images: K as above (chunk ^= (row >> 1) & 7: conflict-free for both MFMA shapes); V rows of 128 B with the 32-byte chunk index
+// ^= ((row >> 1) & 1) << 1 | ((row >> 2) & 1), which makes the half-wave patterns of BOTH shapes conflict-free (this one reads 4 rows
+// x 64 B per half wave, the 16 x 16 one 8 rows x 32 B).
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ int v_swz32(int row) { return (((row >> 1) & 1) << 1) | ((row >> 2) & 1); }
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attention32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int width) {
+    constexpr int T = 257, NKB = 9, TP = NKB * 32, NTH = NW * 64, NCH = (TP * 8 + NTH - 1) / NTH, NQT = (T + 31) / 32;
+    constexpr float LOG2E = 1.4426950408889634f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = smem + TP * 128;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ld = 3 * width;
+    const bf16_t* base = qkv + (size_t)b * T * ld + h * 64;
+    const int r32 = lane & 31, hh = lane >> 5;
+
+    // first query tile of this wave: its loads go out before the K / V staging so that their latency overlaps it
+    bf16x8 qn[4];
+    {
+        const int q0 = wid * 32 + r32;
+        const int qc = q0 < T ? q0 : T - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qn[ks] = *(const bf16x8*)(base + (size_t)qc * ld + ks * 16 + hh * 8);
+    }
+    {
+        uint4 kv[NCH], vv[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + i * NTH;
+            const int row = idx >> 3, c = idx & 7;
+            const int rc = row < T ? row : T - 1;
+            kv[i] = *(const uint4*)(base + (size_t)rc * ld + width + c * 8);
+            vv[i] = *(const uint4*)(base + (size_t)rc * ld + 2 * width + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + i * NTH;
+            const int row = idx >> 3, c = idx & 7;
+            if (idx < TP * 8) {
+                const unsigned keep = row < T ? 0xffffffffu : 0u;
+                uint4 a = kv[i], b2 = vv[i];
+                a.x &= keep; a.y &= keep; a.z &= keep; a.w &= keep;
+                b2.x &= keep; b2.y &= keep; b2.z &= keep; b2.w &= keep;
+                *(uint4*)(sK + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = a;
+                *(uint4*)(sV + row * 128 + ((((c >> 1) ^ v_swz32(row)) << 5) | ((c & 1) << 4))) = b2;
+            }
+        }
+    }
+    __syncthreads();
+
+    // per-lane LDS offsets that do not depend on the block: K row r32, V rows 4 hh + (i >> 2) and columns of the lane's 16-lane group
+    const int kswz = (r32 >> 1) & 7;
+    const int vi = lane & 15, vg = (lane >> 4) & 1;
+    for (int qt = wid; qt < NQT; qt += NW) {           // wave-uniform trip count: EXEC stays full for the tr reads
+        const int q = qt * 32 + r32;
+        bf16x8 qf[4] = {qn[0], qn[1], qn[2], qn[3]};
+        if (qt + NW < NQT) {
+            const int q2 = q + NW * 32;
+            const int qc = q2 < T ? q2 : T - 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qn[ks] = *(const bf16x8*)(base + (size_t)qc * ld + ks * 16 + hh * 8);
+        }
+        // ---- S^T: nine blocks of 32 keys, K fragments of the next block in flight while this block's four MFMAs issue
+        f32x16 s[NKB];
+        bf16x8 kfr[2][4];
+        auto load_k = [&](int kb, bf16x8 (&dst)[4]) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                dst[ks] = *(const bf16x8*)(sK + (kb * 32 + r32) * 128 + (((ks * 2 + hh) ^ kswz) << 4));
+        };
+        load_k(0, kfr[0]);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb + 1 < NKB) load_k(kb + 1, kfr[(kb + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb & 1][ks], qf[ks], s[kb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // s[kb][r] = S[query r32][key kb*32 + (r & 3) + 8 (r >> 2) + 4 hh]; of the last block only key 256 exists
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (kb == NKB - 1) {
+                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    s[kb][r] = key < T ? s[kb][r] : -INFINITY;
+                }
+                mx = fmaxf(mx, s[kb][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mxl = mx * LOG2E;
+        f32x2_t sum2 = {0.f, 0.f};
+        const f32x2_t l2 = {LOG2E, LOG2E}, nm = {-mxl, -mxl};
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2_t a = f32x2_t{s[kb][r], s[kb][r + 1]} * l2 + nm;
+                a.x = __builtin_amdgcn_exp2f(a.x);
+                a.y = __builtin_amdgcn_exp2f(a.y);
+                s[kb][r] = a.x;
+                s[kb][r + 1] = a.y;
+                sum2 += a;
+            }
+        float sum = sum2.x + sum2.y;
+        sum += __shfl_xor(sum, 32);
+
+        // ---- O^T += V^T . P^T: per block two 16-key steps x two 32-row halves of d
+        f32x16 o[2];
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dh][r] = 0.f;
+        auto load_v = [&](int kb, int st, bf16x8 (&dst)[2]) {
+            const int ra = kb * 32 + 16 * st + 4 * hh + (vi >> 2), rb = ra + 8;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh) {
+                const int c32 = dh * 2 + vg;
+                const bf16x4 va = lds_read_tr16(sV + ra * 128 + ((c32 ^ v_swz32(ra)) << 5) + (vi & 3) * 8);
+                const bf16x4 vb = lds_read_tr16(sV + rb * 128 + ((c32 ^ v_swz32(rb)) << 5) + (vi & 3) * 8);
+                dst[dh][0] = va[0]; dst[dh][1] = va[1]; dst[dh][2] = va[2]; dst[dh][3] = va[3];
+                dst[dh][4] = vb[0]; dst[dh][5] = vb[1]; dst[dh][6] = vb[2]; dst[dh][7] = vb[3];
+            }
+        };
+        constexpr int NST = 2 * NKB - 1;                // the last block's second step holds pad keys only
+        bf16x8 vfr[2][2];
+        load_v(0, 0, vfr[0]);
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int kb = u >> 1, st = u & 1;
+            if (u + 1 < NST) load_v((u + 1) >> 1, (u + 1) & 1, vfr[(u + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            union { bf16x8 v; uint32_t w[4]; } pf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pf.w[j] = pack_bf16x2(s[kb][8 * st + 2 * j], s[kb][8 * st + 2 * j + 1]);
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+                o[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[u & 1][dh], pf.v, o[dh], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // o[dh][r] = O[query r32][d = 32 dh + (r & 3) + 8 (r >> 2) + 4 hh]
+        if (q < T) {
+            const float inv = 1.0f / sum;
+            bf16_t* dst = out + ((size_t)b * T + q) * width + h * 64 + 4 * hh;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(o[dh][4 * rg] * inv, o[dh][4 * rg + 1] * inv);
+                    pk.y = pack_bf16x2(o[dh][4 * rg + 2] * inv, o[dh][4 * rg + 3] * inv);
+                    *(uint2*)(dst + 32 * dh + 8 * rg) = pk;
+                }
+        }
+    }
+}
+
+// Measured (round 3, B = 255 x 16 heads, same device; profiles/r03_v2_attention_pmc.txt): 172 us against the 16-query kernel's 165.
+// Per launch it issues 11 % fewer VALU and 47 % fewer LDS instructions (23.9 M / 4.2 M against 26.8 M / 7.9 M) at the same MFMA
+// work, yet its waves spend 43 % of their cycles issue-stalled (SQ_WAIT_INST_ANY) where the 16-query kernel's spend 32 %: with 1.4
+// waves per SIMD on average neither hides the MFMA -> VALU -> MFMA dependence of a tile (S^T, softmax, PV), and the longer 32 x 32
+// chains expose more of it.  What is missing is a second tile in flight per wave, not fewer instructions.  Kept behind the
+// debug switch attn_v = 1 with its tests; the default stays the 16-query kernel.
+int g_attn_v = 0;          // tools: 0 = the 16-query-tile kernel (default), 1 = 32-query tiles on the 32x32x16 MFMA at T = 257
+
 int g_attn_waves = 0;      // tools: 0 = the default choice below, else waves per workgroup for the 257-token shape (4 or 6)
 
 template <int NT32>
@@ -224,6 +411,12 @@ static int launch_nt(const bf16_t* qkv, bf16_t* out, int batch, int t, int width
     if (causal) {
         if (NT32 == 3 && t == 77) { kern = attention_kernel<NT32, true, NT32 == 3 ? 77 : 0, NT32 == 3 ? 5 : 4>; threads = 320; }
         else kern = attention_kernel<NT32, true, 0>;
+    } else if (NT32 == 9 && t == 257 && g_attn_v == 1) {
+        auto k32 = attention32_kernel<4>;
+        KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)k32, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        hipLaunchKernelGGL(k32, grid, dim3(256), smem, stream, qkv, out, width);
+        KEMR_CHECK_LAUNCH("attention32_kernel");
+        return KEMR_OK;
     } else if (NT32 == 9 && t == 257) {
         if (g_attn_waves == 6) { kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, NT32 == 9 ? 6 : 4>; threads = 384; }
         else kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0>;

@@ -143,6 +143,7 @@ extern int g_gemm_dbg;
 extern int g_gemm_order;
 extern int g_sim_lists;     // sim.hip: candidate-list route of kemr_sim_topk (kemr_debug_set "sim_lists")
 extern int g_attn_waves;    // attention.hip (tools)
+extern int g_attn_v;        // attention.hip (tools): 1 = 32-query tiles on the 32x32x16 MFMA at T = 257
 extern int g_gemm_kl;       // gemm256u: 1 = long-interval K loop (round 3, default), 0 = round 2's (tools/ A/B)
 extern int g_gemm_conc;     // gemm256u: both wave halves run their epilogues in the same barrier interval (0 never, 1 always, 2 = QuickGELU epilogue only)
 int gemm_read_stamps(unsigned* host_out, int n_words);

@@ -163,6 +163,21 @@ class CollateAndTokenize:
     def __init__(self, tokenize_fn):
         self.tokenize_fn = tokenize_fn
 
+    # Workers started from a fork server (evaluators.loader_context) import this package afresh: the opt-ins the parent made with
+    # allow_hash_tokenizer() / allow_random_weights() travel with the collate object instead of with forked module globals.
+    def __getstate__(self):
+        from . import clip_api, tokenizer
+        return {"tokenize_fn": self.tokenize_fn, "allow_hash": tokenizer.hash_tokenizer_allowed(), "allow_random": clip_api.random_weights_allowed()}
+
+    def __setstate__(self, state):
+        self.tokenize_fn = state["tokenize_fn"]
+        if state.get("allow_hash") or state.get("allow_random"):
+            from . import clip_api, tokenizer
+            if state.get("allow_hash"):
+                tokenizer.allow_hash_tokenizer(True)
+            if state.get("allow_random"):
+                clip_api.allow_random_weights(True)
+
     def __call__(self, batch):
         images, queries, targets, uuids = collate_fn_eval(batch)
         return images, self.tokenize_fn(queries), self.tokenize_fn(targets), uuids

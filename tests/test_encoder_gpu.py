@@ -184,14 +184,16 @@ def test_residual_fusion_switch(device, precision):
     px = torch.randn(40, 3, arch.image_size, arch.image_size, generator=g)            # 2 000 token rows: the persistent GEMM's side of the switch
     ids = clip_ref.synthetic_ids(oa, 24)
     ref_i, ref_t = clip_ref.encode_image(sd, oa, px[:4]), clip_ref.encode_text(sd, oa, ids[:4])
-    assert eng.residual_fusion() and other.residual_fusion()
+    assert eng.residual_fusion() == 1 and other.residual_fusion() == 1               # the default level: bf16 streams only
+    assert eng.residual_fusion_active() == (precision == "bf16-res16")
+    level = 1 if precision == "bf16-res16" else 2                                     # fp32 streams fuse at level 2 only (slower: opt-in)
     outs = {}
     for on in (True, False):
-        eng.set_residual_fusion(on)
-        assert eng.residual_fusion() == on and other.residual_fusion()
+        eng.set_residual_fusion(level if on else 0)
+        assert eng.residual_fusion() == (level if on else 0) and eng.residual_fusion_active() == on and other.residual_fusion() == 1
         outs[on] = (eng.encode_image(px.to(device)).cpu(), eng.encode_text(ids.to(device)).cpu())
         assert float((1 - _cos(outs[on][0][:4], ref_i)).max()) < COS_TOL and float((1 - _cos(outs[on][1][:4], ref_t)).max()) < COS_TOL
-    assert torch.equal(other.encode_image(px.to(device)).cpu(), outs[True][0])          # untouched by eng's switch
+    assert torch.equal(other.encode_image(px.to(device)).cpu(), outs[precision == "bf16-res16"][0])          # untouched by eng's switch
     assert not torch.equal(outs[True][0], outs[False][0])
     close = 3e-4 if precision == "bf16-res16" else 2e-5
     assert float((1 - _cos(outs[True][0], outs[False][0])).max()) < close and float((1 - _cos(outs[True][1], outs[False][1])).max()) < close

@@ -301,3 +301,24 @@ def test_tile_friendly_batch_sizes():
     assert engine.tile_friendly_batch(77, 768, 255, 851) == 851
     assert engine.tile_friendly_batch(77, 768, 255, 300) in range(255, 301)
     assert engine.tile_friendly_batch(77, 512, 100, 100) == 100
+
+
+def test_importing_the_loader_side_never_initialises_the_gpu():
+    """The loader processes (fork server, evaluators.loader_context) import the package afresh; nothing on that import path may call
+    into HIP -- torch.cuda.is_available() included: round 3 had it in a default argument of clip_api.load, and the box's process
+    guard counted 13 processes with the GPU open."""
+    import subprocess
+    import sys
+    code = (
+        "import torch\n"
+        "def boom(*a, **k):\n    raise AssertionError('HIP touched at import')\n"
+        "torch.cuda.is_available = boom; torch.cuda.device_count = boom; torch.cuda.current_device = boom\n"
+        "import importlib\n"
+        "from knowledge_enhanced_multimodal_retrieval_amd import evaluators\n"
+        "for m in evaluators._FORKSERVER_PRELOAD + ['knowledge_enhanced_multimodal_retrieval_amd.clip_api', 'clip', 'src.clip.eval.evaluator']:\n"
+        "    importlib.import_module(m)\n"
+        "assert not torch.cuda.is_initialized()\n"
+        "print('clean')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=120)
+    assert r.returncode == 0 and "clean" in r.stdout, r.stderr[-800:]

@@ -417,3 +417,52 @@ def test_attention_softmax_spike(device):
     got = engine.op_attention(qkv_bf.to(device), batch, t, width, False).float().cpu()
     assert torch.isfinite(got).all()
     assert float((got - ref).abs().max()) < 3e-2
+
+
+@pytest.mark.parametrize("batch,width", [(3, 256), (9, 1024)])
+def test_attention_257_both_kernels_and_exact_structure(device, batch, width):
+    """T = 257 (the vision towers' shape): the 16-query-tile kernel (default) and round 3's 32-query tiles on
+    v_mfma_f32_32x32x16_bf16 (debug switch attn_v = 1).  Both against the fp32 torch statement; then EXACT structure with
+    integer-valued data that bf16 and fp32 hold exactly -- a one-hot softmax (one key 40 logits ahead per query) must return that
+    key's V row, for every query of every tile including the lone 257th, which catches a wrong key <-> k-slot permutation or V
+    transposition outright (the other 256 keys weigh e^-40: they move a zero entry by 1e-17 and nothing else)."""
+    from knowledge_enhanced_multimodal_retrieval_amd import debug
+    t = 257
+    g = torch.Generator().manual_seed(batch + width)
+    qkv = torch.randn(batch * t, 3 * width, generator=g)
+    qkv[:, :width] *= 0.25
+    qkv_bf = qkv.to(torch.bfloat16)
+    ref = _attention_ref(qkv_bf, batch, t, width, False)
+    outs = {}
+    for v in (0, 1):
+        with debug.override(attn_v=v):
+            outs[v] = engine.op_attention(qkv_bf.to(device), batch, t, width, False).float().cpu()
+        assert float((outs[v] - ref).abs().max()) < 3e-2 and float((outs[v] - ref).abs().mean()) < 3e-3, v
+    assert float((outs[0] - outs[1]).abs().max()) < 2e-2
+    # one-hot: query i of head hd looks for key perm[i]: q = 64 * e_(c(i)), k_j = e_(c'(j)) built so that q_i . k_j = 64 iff j == perm[i]
+    heads = width // 64
+    perm = torch.randperm(t, generator=g)
+    x = torch.zeros(batch * t, 3 * width)
+    vals = torch.randint(-64, 65, (batch * t, width), generator=g).float()            # exact in bf16
+    x[:, 2 * width:] = vals
+    code = torch.arange(t)                                                             # 257 codes as 2 base-17 digits -> two one-hot groups of 17 dims
+    d0, d1 = code % 17, code // 17
+    for hd in range(heads):
+        kk = torch.zeros(t, 64)
+        kk[torch.arange(t), d0] = 1.0
+        kk[torch.arange(t), 17 + d1] = 1.0
+        qq = torch.zeros(t, 64)
+        qq[torch.arange(t), d0[perm]] = 40.0
+        qq[torch.arange(t), 17 + d1[perm]] = 40.0          # q_i . k_j = 80 when j == perm[i], 40 or 0 otherwise: exp(-40) of the rest vanishes under fp32 sums
+        for b in range(batch):
+            x[b * t:(b + 1) * t, hd * 64:(hd + 1) * 64] = qq
+            x[b * t:(b + 1) * t, width + hd * 64:width + (hd + 1) * 64] = kk
+    xb = x.to(torch.bfloat16)
+    want = torch.empty(batch * t, width)
+    for b in range(batch):
+        want[b * t:(b + 1) * t] = vals[b * t:(b + 1) * t][perm]
+    for v in (0, 1):
+        with debug.override(attn_v=v):
+            got = engine.op_attention(xb.to(device), batch, t, width, False).float().cpu()
+        assert float((got - want).abs().max()) < 1e-6, (v, float((got - want).abs().max()))
+

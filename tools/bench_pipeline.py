@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--loader-only", action="store_true", help="iterate the loader without the GPU work: the host-side ceiling")
     ap.add_argument("--trace", action="store_true", help="host seconds spent inside the preprocess / encoder calls (no syncs added)")
     ap.add_argument("--host-transform", action="store_true", help="the reference's arrangement: PIL transform in the loader")
+    ap.add_argument("--hf-split", action="store_true", help="PIL images through CLIPEvalDatasetHF(split, preprocess), the reference's dataset call (what the CLIs and bench.py's pipeline leg run)")
     args = ap.parse_args()
     import clip
     from knowledge_enhanced_multimodal_retrieval_amd import datasets, evaluators
@@ -50,7 +51,9 @@ def main():
         warnings.simplefilter("ignore")
         model, preprocess = clip.load(args.model, device="cuda")
     ds = datasets.SyntheticRawImageDataset(args.n)
-    if args.host_transform:
+    if args.hf_split:
+        use = datasets.CLIPEvalDatasetHF(datasets.SyntheticHFSplit(args.n), preprocess)
+    elif args.host_transform:
         from PIL import Image
 
         class Host(torch.utils.data.Dataset):
