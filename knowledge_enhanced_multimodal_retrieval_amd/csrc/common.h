@@ -147,8 +147,8 @@ extern int g_attn_v;        // attention.hip (tools): 1 = 32-query tiles on the 
 extern int g_gemm_kl;       // gemm256u: 1 = long-interval K loop (round 3, default), 0 = round 2's (tools/ A/B)
 extern int g_gemm_conc;     // gemm256u: both wave halves run their epilogues in the same barrier interval (0 never, 1 always, 2 = QuickGELU epilogue only)
 int gemm_read_stamps(unsigned* host_out, int n_words);
-int launch_gemm256u_simgmax(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, float* out, hipStream_t stream,
-                            bool* used);
+int launch_gemm256u_simgmax(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, int stride, float* out,
+                            hipStream_t stream, bool* used);
 struct SimkPlan { int nchunks, tpc, cap; size_t scores_bytes, base_bytes, count_bytes; };
 int gemm256u_simk_plan(int nq, int ng, int kdim, double hits_per_query, double spread, SimkPlan* plan, bool* ok);
 int launch_gemm256u_simk(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, long long gallery_offset,

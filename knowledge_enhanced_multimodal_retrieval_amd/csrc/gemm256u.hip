@@ -1234,17 +1234,19 @@ int launch_gemm256u_simk(const bf16_t* q_panel, int nq, const bf16_t* g_panel, i
     return launch_sim_mode<2>(p, q_tiles, stream);
 }
 
-// Group maxima (SIM == 3): out[nq][ceil256(ng) / 64] = the best score of every query within each block of 64 gallery rows.
-// g_panel must be padded to whole 256-row tiles with REAL rows (the caller samples a multiple of 256).
-int launch_gemm256u_simgmax(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, float* out, hipStream_t stream,
-                            bool* used) {
+// Group maxima (SIM == 3): out[nq][ng / 64] = the best score of every query within each block of 64 sampled gallery rows.
+// The sample is rows 0, stride, 2 stride, ... of g_panel, read in place through the W operand's leading dimension (ng rows, a
+// multiple of 256, all REAL: ng * stride <= the panel's valid rows) -- no copy of the sample, one launch fewer (round 3).
+int launch_gemm256u_simgmax(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, int stride, float* out,
+                            hipStream_t stream, bool* used) {
     *used = false;
-    if (ng % 256 != 0) KEMR_FAIL(KEMR_ERR_INVALID, "simgmax: %d gallery rows are not whole tiles", ng);
+    if (ng % 256 != 0 || stride < 1) KEMR_FAIL(KEMR_ERR_INVALID, "simgmax: %d sampled rows are not whole tiles (stride %d)", ng, stride);
+    if ((long)ng * stride * kdim * 2 >= (1L << 32)) return KEMR_OK;          // 32-bit W offsets
     int tpc = 0;
     const int nch = sim_chunking(nq, ng, kdim, 0, &tpc);
     if (nch <= 0) return KEMR_OK;
     GemmParams p{};
-    p.A = q_panel; p.lda = kdim; p.W = g_panel; p.ldw = kdim; p.M = nq; p.N = ng; p.K = kdim;
+    p.A = q_panel; p.lda = kdim; p.W = g_panel; p.ldw = kdim * stride; p.M = nq; p.N = ng; p.K = kdim;
     p.sim_ng = ng; p.sim_tpc = tpc; p.sim_nchunks = nch;
     p.simk_scores = out;
     KEMR_TRY(launch_sim_mode<3>(p, (nq + 255) / 256, stream));

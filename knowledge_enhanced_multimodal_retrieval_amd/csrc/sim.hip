@@ -442,7 +442,7 @@ extern "C" int kemr_panel_build(const float* const* parts_dev, const float* part
 
 // ------------------------------------------------------------------------------------------------ top-k by candidate lists
 // Large galleries: the scores come out of the persistent GEMM's K loop (gemm256u.hip, SIM == 2) instead of sim_kernel.
-//   1. thresholds: a strided SAMPLE of the gallery (m rows, from k: simk_layout) goes through the same K loop, which keeps the best
+//   1. thresholds: a strided SAMPLE of the gallery (m rows, from k: simk_layout; read in place with a row stride) goes through the same K loop, which keeps the best
 //      score of every query within each block of 64 sampled rows (SIM == 3); the k-th largest of these block maxima is the
 //      score of k distinct gallery items, hence a lower bound of the k-th score of the gallery: every member of the true
 //      top-k scores >= it -- whatever the data, the lists below contain the answer.
@@ -451,16 +451,6 @@ extern "C" int kemr_panel_build(const float* const* parts_dev, const float* part
 //   3. one wave per query picks the k best of its lists' entries with the path's order rule (score desc, id asc).
 // A list that overflows (thresholds far too low: e.g. thousands of equal scores) raises a flag, and the sim_kernel path
 // then runs after all: its launches are always queued and exit at once while the flag is clear (no host round trip).
-__global__ __launch_bounds__(256) void sample_rows_kernel(const bf16_t* __restrict__ G, int ng, int kdim, int m,
-                                                          bf16_t* __restrict__ out) {
-    const int per_row = kdim >> 3;                                   // 16-byte pieces
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)m * per_row) return;
-    const int j = (int)(i / per_row), c = (int)(i - (long long)j * per_row);
-    const long long src = (long long)j * ng / m;                     // strided sample, distinct rows (ng >= m)
-    ((uint4*)out)[i] = ((const uint4*)(G + (size_t)src * kdim))[c];
-}
-
 // one wave per query: k-th largest of its <= 128 block maxima (k rounds of "wave maximum, remove one instance")
 __global__ __launch_bounds__(256) void simk_threshold_kernel(const float* __restrict__ gmax, int nq, int groups, int k,
                                                              float* __restrict__ taud, int32_t* __restrict__ flag) {
@@ -579,6 +569,62 @@ __global__ __launch_bounds__(256) void simk_select_kernel(const float* __restric
     }
 }
 
+// Rank-only passes WITH a bonus list (the alpha sweep of the SPARQL score fusion, evaluator.py:164-218 -> eval/fusion.py:22-85: nine
+// passes over the 43 000 x 43 000 problem per weight setting) take the fast rank-count pass on the RAW scores against the ground
+// truth's fused score, and this kernel then corrects the count for the few candidates that carry a bonus: one wave per query walks
+// its CSR row 16 entries at a time, recomputes those candidates' raw scores with the tile kernels' arithmetic (same MFMA, same
+// operand roles and k order as pair_scores_kernel: bit-identical), and moves each from the side of the ground truth its raw score
+// put it on to the side its fused score puts it on.  Entries of one candidate (equal columns) add up in list order, as in
+// sim_kernel's scanner; the ground truth itself and candidates outside this gallery are skipped.
+__global__ __launch_bounds__(64) void bonus_rank_fixup_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ G, int nq, int ng,
+                                                              int kdim, long long goff, const int32_t* __restrict__ brow,
+                                                              const int32_t* __restrict__ bcol, const float* __restrict__ bval,
+                                                              const int32_t* __restrict__ gt_idx, const float* __restrict__ gt_score,
+                                                              int32_t* __restrict__ ahead) {
+    const int q = blockIdx.x;
+    const int lane = threadIdx.x & 63, lrow = lane & 15, lq = lane >> 4;
+    const int e0 = brow[q], e1 = brow[q + 1];
+    if (e0 >= e1) return;
+    const float g = gt_score[q];
+    const int gt = gt_idx[q];
+    const bf16_t* qp = Q + (size_t)q * kdim + lq * 8;
+    int delta = 0;
+    for (int base = e0; base < e1; base += 16) {
+        const int e = base + lrow;
+        const int col = e < e1 ? bcol[e] : -1;
+        const long long loc = (long long)col - goff;
+        const bool inside = e < e1 && loc >= 0 && loc < ng;
+        const bf16_t* gp = G + (size_t)(inside ? loc : 0) * kdim + lq * 8;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < kdim; k0 += 32) {
+            const bf16x8 gf = *(const bf16x8*)(gp + k0);
+            const bf16x8 qf = *(const bf16x8*)(qp + k0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, qf, acc, 0, 0, 0);
+        }
+        // D[candidate i][query column]: every column is this query; lanes with lrow == 0 hold candidates 4 lq .. 4 lq + 3
+        if (lrow == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ee = base + lq * 4 + r;
+                if (ee >= e1) continue;
+                const int c = bcol[ee];
+                const long long lc = (long long)c - goff;
+                if (lc < 0 || lc >= ng || c == gt) continue;
+                if (ee > e0 && bcol[ee - 1] == c) continue;              // not the first entry of this candidate's run
+                float fused = acc[r];
+                for (int t = ee; t < e1 && bcol[t] == c; ++t) fused += bval[t];
+                const float raw = acc[r];
+                const int before = (raw > g || (raw == g && c < gt)) ? 1 : 0;
+                const int after = (fused > g || (fused == g && c < gt)) ? 1 : 0;
+                delta += after - before;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) delta += __shfl_xor(delta, off);
+    if (lane == 0 && delta != 0) ahead[q] += delta;
+}
+
 namespace kemr { int g_sim_lists = 1; }
 
 static int sim_chunks(int nq, int ng, int* tiles_per_chunk) {
@@ -600,15 +646,16 @@ static size_t sim_lists_bytes(int nq, int ng, int k) {
 // workspace of the candidate-list path (behind the sim_kernel path's own lists, which its fallback needs)
 struct SimkLayout {
     bool on = false;
-    int m = 0;                     // sampled gallery rows
+    int m = 0, stride = 1;         // sampled gallery rows: 0, stride, 2 stride, ...
     SimkPlan plan{};
-    size_t off_sample = 0, off_gmax = 0, off_taud = 0, off_flag = 0, off_count = 0, off_base = 0, off_scores = 0, bytes = 0;
+    size_t off_gmax = 0, off_taud = 0, off_flag = 0, off_count = 0, off_base = 0, off_scores = 0, bytes = 0;
 };
 
 static SimkLayout simk_layout(int nq, int ng, int64_t kdim, int k) {
     SimkLayout L;
     L.bytes = sim_lists_bytes(nq, ng, k);
-    if (k < 1 || nq < 256 || ng < 8192 || kdim % 64 != 0 || kdim < 128 || kdim > 65536) return L;
+    // from 2 048 gallery rows up (round 2: 8 192): an 8-way shard of the 43 000 gallery has 5 375 rows (BASELINE configs[3])
+    if (k < 1 || nq < 256 || ng < 2048 || kdim % 64 != 0 || kdim < 128 || kdim > 65536) return L;
     // Sampled rows m: the entries >= threshold a query brings to the selection number about 1.15 k ng / m (the k-th block
     // maximum sits a little below the k-th item of the sample; measured 1.1x), Gamma(k)-distributed around that mean: the
     // smaller k, the longer the tail (k = 1: exponential).  spread(k) ~ the 1 - 1e-8 quantile over the mean (20.5 / 6.3 / 4.1 /
@@ -619,14 +666,14 @@ static SimkLayout simk_layout(int nq, int ng, int64_t kdim, int k) {
     const double mean_max = SIMK_SELECT / spread;
     int m = (int)round_up((int64_t)ceil(1.15 * k * (double)ng / mean_max), 256);
     const int m_min = (int)round_up(64 * (int64_t)k, 256);                     // k block maxima need k blocks of 64 rows
-    m = m < 1024 ? 1024 : m;
+    m = m < 512 ? 512 : m;
     m = m < m_min ? m_min : m;
-    if (m > 8192) return L;
+    if (m > 8192 || 2 * m > ng) return L;            // at most half the gallery as the sample (the sample pass costs m / ng of the list pass)
+    L.stride = ng / m;                               // rows 0, stride, ... (m - 1) stride: distinct, all < ng
     bool ok = false;
     if (gemm256u_simk_plan(nq, ng, (int)kdim, 1.15 * k * ng / m, spread, &L.plan, &ok) != KEMR_OK || !ok) return L;
     size_t at = L.bytes;
     auto take = [&](size_t b) { const size_t o = at; at += (size_t)round_up((int64_t)b, 256); return o; };
-    L.off_sample = take((size_t)m * kdim * 2);
     L.off_gmax = take((size_t)nq * (m / 64) * 4);
     L.off_taud = take((size_t)nq * 4);
     L.off_flag = take(4);
@@ -698,24 +745,25 @@ extern "C" int kemr_sim_topk(const void* q_panel_dev, int nq, const void* g_pane
     p.gt_idx = gt_idx_dev; p.gt_score = gt_score_dev; p.ahead = ahead_dev;
     p.brow = bonus_rowptr_dev; p.bcol = bonus_col_dev; p.bval = bonus_val_dev;
     hipStream_t s = (hipStream_t)stream;
-    if (k == 0 && !bonus_rowptr_dev) {        // ranks only: the 256 x 256-tile pass on the persistent GEMM's K loop (gemm256u.hip, SIM)
+    if (k == 0 && (!bonus_rowptr_dev || g_sim_lists)) {        // ranks only: the 256 x 256-tile pass on the persistent GEMM's K loop (gemm256u.hip, SIM)
         bool used = false;
         KEMR_TRY(launch_gemm256u_simrank(p.Q, nq, p.G, ng, (int)kdim, gallery_offset, gt_idx_dev, gt_score_dev, ahead_dev, s, &used));
-        if (used) return KEMR_OK;
+        if (used) {
+            if (bonus_rowptr_dev) {            // + the candidates that carry a bonus change sides where their fused score says so
+                hipLaunchKernelGGL(bonus_rank_fixup_kernel, dim3(nq), dim3(64), 0, s, p.Q, p.G, nq, ng, (int)kdim, (long long)gallery_offset,
+                                   bonus_rowptr_dev, bonus_col_dev, bonus_val_dev, gt_idx_dev, gt_score_dev, ahead_dev);
+                KEMR_CHECK_LAUNCH("bonus_rank_fixup_kernel");
+            }
+            return KEMR_OK;
+        }
     }
     if (L.on && g_sim_lists) {                // top-k (and ranks) through candidate lists: see above
         char* ws = (char*)workspace_dev;
-        bf16_t* sample = (bf16_t*)(ws + L.off_sample);
         float* gmax = (float*)(ws + L.off_gmax);
         float* taud = (float*)(ws + L.off_taud);
         int32_t* flag = (int32_t*)(ws + L.off_flag);
-        {
-            const long long pieces = (long long)L.m * (kdim >> 3);
-            hipLaunchKernelGGL(sample_rows_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, p.G, ng, (int)kdim, L.m, sample);
-            KEMR_CHECK_LAUNCH("sample_rows_kernel");
-        }
         bool used = false;
-        KEMR_TRY(launch_gemm256u_simgmax(p.Q, nq, sample, L.m, (int)kdim, gmax, s, &used));
+        KEMR_TRY(launch_gemm256u_simgmax(p.Q, nq, p.G, L.m, (int)kdim, L.stride, gmax, s, &used));
         if (!used) KEMR_FAIL(KEMR_ERR_STATE, "sim_topk: the sample pass does not fit the kernel that the plan accepted");
         hipLaunchKernelGGL(simk_threshold_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, gmax, nq, L.m / 64, k, taud, flag);
         KEMR_CHECK_LAUNCH("simk_threshold_kernel");

@@ -205,7 +205,7 @@ def hf_full_shape():
         del m
 
 
-E2E_CASES = (("ViT-B/32", 256, (2.0, 3.0, 4.0)), ("ViT-L/14", 64, (2.0, 3.0)))     # (architecture, gallery items, noise levels of the image queries)
+E2E_CASES = (("ViT-B/32", 256, (2.0, 3.0, 4.0)), ("ViT-L/14", 32, (3.0,)))     # (architecture, gallery items, noise levels of the image queries)
 
 
 def e2e_inputs(arch, n, levels):

@@ -271,9 +271,12 @@ def _lists_mode(mode):
 
 
 @pytest.mark.parametrize("nq,ng,d,terms,off,k", [(300, 9000, 128, 1, 0, 10), (257, 16000, 128, 1, 5, 5), (600, 20001, 192, 3, 1000, 32),
-                                                 (256, 8192, 64, 1, 0, 1), (1024, 43000, 768, 1, 0, 10), (43000, 43000, 768, 1, 0, 10)])
+                                                 (256, 8192, 64, 1, 0, 1), (1024, 43000, 768, 1, 0, 10), (43000, 43000, 768, 1, 0, 10),
+                                                 (1024, 5375, 768, 1, 37625, 10), (300, 2048, 128, 1, 0, 10), (256, 2500, 64, 3, 5, 5)])
 def test_topk_by_candidate_lists_is_the_kernel_path_bit_for_bit(device, nq, ng, d, terms, off, k):
-    """The headline leg included (Q = 43 000 against the 43 000 gallery: 4 096 sampled rows, three gallery chunks per query tile).
+    """The headline leg included (Q = 43 000 against the 43 000 gallery: 4 096 sampled rows, three gallery chunks per query tile), and
+    since round 3 the small galleries: an 8-way shard of the 43 000 (5 375 rows at offset 7 x 5 375, BASELINE configs[3]) and the
+    route's lower end (2 048 rows); the sample is read in place with a row stride.
     >= 8192 gallery rows and >= 256 queries: thresholds from a 1/12 sample, candidate lists out of the 256 x 256-tile pass,
     selection (sim.hip).  Scores, ids and rank counts must equal (a) sim_kernel's on the same panels and (b) a stable
     descending sort of the dense scores of the same arithmetic -- with exact ties around the ground truth, a ragged last tile,
@@ -428,3 +431,70 @@ def test_single_query_search_equals_batched(device):
     for j in (0, 129):
         s1, i1 = engine.sim_topk(engine.build_panel([qs[j:j + 1]], _lib.SIDE_QUERY, 1), gp, 10)
         assert torch.equal(i1[0], bi[j]) and torch.equal(s1[0], bs[j])
+
+
+
+@pytest.mark.parametrize("nq,ng,d,terms,off", [(700, 9000, 128, 1, 0), (300, 5375, 192, 3, 16125), (1000, 43000, 768, 1, 0)])
+def test_rank_only_with_bonus_list_takes_the_fast_pass_plus_fixup(device, nq, ng, d, terms, off):
+    """The alpha sweep of the SPARQL score fusion (evaluator.py:164-218) asks for ranks under score + sparse bonus.  Since round 3:
+    the rank-count pass of the persistent GEMM's K loop on the RAW scores, then a per-query fix-up of the candidates that carry a
+    bonus (csrc/sim.hip bonus_rank_fixup_kernel).  The counts must equal sim_kernel's bonus scanner (debug switch sim_lists = 0)
+    and a dense statement of the rule -- with duplicated entries of one candidate, a bonus on the ground truth itself, entries
+    outside this shard, bonuses that lift a candidate exactly onto the ground truth's score (tie broken by id) and negative ones."""
+    g = torch.Generator().manual_seed(nq + ng)
+    gal = torch.nn.functional.normalize(torch.randn(ng, d, generator=g), dim=-1)
+    gt = torch.randint(0, ng, (nq,), generator=g)
+    qry = torch.nn.functional.normalize(gal[gt] + 0.8 * torch.randn(nq, d, generator=g), dim=-1)
+    gal, qry, gt = gal.to(device), qry.to(device), gt.to(device)
+    qp = engine.build_panel([qry], _lib.SIDE_QUERY, terms, part_scale=[0.7])
+    gp = engine.build_panel([gal], _lib.SIDE_GALLERY, terms)
+    raw_gt = engine.pair_scores(qp, gp, torch.arange(nq, device=device).int(), gt.int())
+    S = engine.scores_dense(qp, gp) if nq * ng <= 2e7 else None
+    # CSR: every third query has hits; columns are GLOBAL ids (off + local), some outside [off, off + ng)
+    ptr, cols, vals = [0], [], []
+    rng = np.random.default_rng(nq)
+    gt_h = gt.cpu().numpy()
+    for q in range(nq):
+        if q % 3 == 0:
+            n_hit = int(rng.integers(1, 40))
+            c = np.unique(rng.integers(-20, ng + 20, size=n_hit))
+            c = np.sort(np.concatenate([c, c[:2], [gt_h[q]] if q % 6 == 0 else []]).astype(np.int64))      # duplicates; the ground truth itself
+            v = rng.choice([0.3, 0.05, -0.1, 1e-3], size=len(c)).astype(np.float32)
+            if S is not None and q % 9 == 0 and len(c):            # lift one candidate EXACTLY onto the ground truth's fused score
+                j = int(c[len(c) // 2])
+                if 0 <= j < ng and j != gt_h[q] and (c == j).sum() == 1:
+                    tgt_score = float(raw_gt[q]) + float(v[c == gt_h[q]].sum()) if (c == gt_h[q]).any() else float(raw_gt[q])
+                    v[np.where(c == j)[0][0]] = np.float32(np.float32(tgt_score) - np.float32(S[q, j].item()))
+            cols += list(c + off)
+            vals += list(v)
+        ptr.append(len(cols))
+    ptr_t = torch.tensor(ptr, dtype=torch.int32, device=device)
+    col_t = torch.tensor(cols, dtype=torch.int32, device=device)
+    val_t = torch.tensor(vals, dtype=torch.float32, device=device)
+    # the ground truth's fused score: its raw score + its own bonuses, summed in list order (what ranking.py hands to the kernel)
+    sgt = raw_gt.clone()
+    rows = torch.repeat_interleave(torch.arange(nq, device=device), (ptr_t[1:] - ptr_t[:-1]).long())
+    own = col_t.long() == (gt + off)[rows]
+    for e in torch.nonzero(own).flatten().tolist():
+        sgt[rows[e]] = sgt[rows[e]] + val_t[e]
+    gtg = (gt + off).int()
+    out = {}
+    try:
+        for mode in (0, 1):
+            _lists_mode(mode)
+            ahead = torch.zeros(nq, dtype=torch.int32, device=device)
+            engine.sim_topk(qp, gp, 0, off, gtg, sgt, ahead, bonus=(ptr_t, col_t, val_t))
+            out[mode] = ahead
+    finally:
+        _lists_mode(1)
+    assert torch.equal(out[0], out[1])
+    if S is not None:
+        F = S.clone()
+        loc = col_t.long() - off
+        ok = (loc >= 0) & (loc < ng)
+        for e in torch.nonzero(ok).flatten().tolist():             # entries add up in list order
+            F[rows[e], loc[e]] = F[rows[e], loc[e]] + val_t[e]
+        ids = torch.arange(ng, device=device)[None, :]
+        want = (((F > sgt[:, None]) | ((F == sgt[:, None]) & (ids < gt[:, None]))) & (ids != gt[:, None])).sum(1).int()
+        assert torch.equal(out[1], want)
+
