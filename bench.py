@@ -296,76 +296,17 @@ def main():
             n_l = sum(len(b[3]) for b in evaluators.eval_loader(kds.CLIPEvalDatasetHF(kds.SyntheticHFSplit(n_pipe // 2, 13), ppre), 64, 1, workers,
                                                                 evaluators.default_tokenize, True))
             loader_only = 3 * n_l / (time.perf_counter() - t1)
-            spent = {}
-            if os.environ.get("KEMR_BENCH_TRACE"):                         # host seconds inside the consumer's calls (diagnostic)
-                # device time of the consumer's three kinds of call in THIS process, each synchronised
-                from knowledge_enhanced_multimodal_retrieval_amd.preprocess import ClipPreprocessGPU, pack_raw
-                raw = kds.SyntheticRawImageDataset(64, 5)
-                packed = pack_raw([raw[i][0] for i in range(64)]).pin_memory()
-                gp_ = ClipPreprocessGPU(224, dev)
-                gp_.batch(packed); torch.cuda.synchronize()
-                t_ = time.perf_counter()
-                for _ in range(10):
-                    gp_.batch(packed)
-                torch.cuda.synchronize()
-                spent["sync.preprocess_batch_ms"] = (time.perf_counter() - t_) * 100
-                xi = torch.randn(255, 3, 224, 224, device=dev)
-                pm.encode_image(xi, normalize=True); torch.cuda.synchronize()
-                t_ = time.perf_counter()
-                for _ in range(4):
-                    pm.encode_image(xi, normalize=True)
-                torch.cuda.synchronize()
-                spent["sync.encode_image_255_ms"] = (time.perf_counter() - t_) * 250
-                t_ = time.perf_counter()
-                for _ in range(4):
-                    eng.encode_image(xi, normalize=True)
-                torch.cuda.synchronize()
-                spent["sync.main_engine_encode_image_255_ms"] = (time.perf_counter() - t_) * 250
-                def timed(owner, name, key):
-                    fn = getattr(owner, name)
-
-                    def wrapper(*a, **k):
-                        t = time.perf_counter()
-                        try:
-                            return fn(*a, **k)
-                        finally:
-                            spent[key] = spent.get(key, 0.0) + time.perf_counter() - t
-                            spent[key + ".calls"] = spent.get(key + ".calls", 0) + 1
-                    setattr(owner, name, wrapper)
-                import faulthandler
-                faulthandler.dump_traceback_later(8, repeat=False, file=sys.stderr)      # where the consumer sits 8 s into the run
-                _to = torch.Tensor.to
-
-                def to_timed(self_, *a, **k):
-                    t = time.perf_counter()
-                    try:
-                        return _to(self_, *a, **k)
-                    finally:
-                        if self_.dtype == torch.uint8 and self_.dim() == 1:
-                            spent["uint8 .to(device)"] = spent.get("uint8 .to(device)", 0.0) + time.perf_counter() - t
-                            spent["uint8 pinned"] = spent.get("uint8 pinned", 0) + int(self_.is_pinned())
-                torch.Tensor.to = to_timed
-                timed(_lib.lib(), "kemr_preprocess_u8_batch", "C kemr_preprocess_u8_batch")
-                timed(evaluators.ClipPreprocessGPU, "batch", "preprocess.batch")
-                timed(pm, "encode_image", "encode_image")
-                timed(pm, "encode_text", "encode_text")
-                timed(pm, "engine", "engine()")
-                timed(pm._engine.__class__, "load_state_dict", "engine.load_state_dict")
             t1 = time.perf_counter()
             pi, pq, pt, pids = evaluators.encode_dataset(pm, kds.CLIPEvalDatasetHF(split, ppre), 64, 1, workers)
             barrier()
             dtp = time.perf_counter() - t1
             assert pi.shape[0] == n_pipe and len(pids) == n_pipe and bool(torch.isfinite(pi).all())
             result["pipeline"] = {"items_per_s": 3 * n_pipe / dtp, "images_per_s": n_pipe / dtp, "seconds": dtp, "items": n_pipe,
-                                  "loader_workers": workers, "loader_batch": 64, "host_cores": os.cpu_count(), "loader_only_items_per_s": loader_only, **({"host_seconds": spent} if spent else {}),
+                                  "loader_workers": workers, "loader_batch": 64, "host_cores": os.cpu_count(), "loader_only_items_per_s": loader_only, "loader_context": os.environ.get("KEMR_LOADER_CONTEXT", "forkserver"),
                                   "image_transform": "gpu" if ppre.defer_to_gpu else "host",
                                   "source": "uint8 PIL images of 8 camera-like sizes (224x224 .. 600x800) -> CLIPEvalDatasetHF(split, preprocess) -> "
                                             "evaluators.encode_dataset; worker start-up and PCIe included"}
             del pm, pi, pq, pt
-
-    if os.environ.get("KEMR_BENCH_PIPELINE_FIRST"):
-        pipeline_leg()
-        args.no_pipeline = True
 
     # ------------------------------------------------------------------ roofline: per-class hipEvent timing
     L = _lib.lib()
@@ -475,6 +416,11 @@ def main():
                                   "min_bytes": 2 * GALLERY * arch.embed_dim * 2 + GALLERY * 10 * 8}
 
     # ------------------------------------------------------------------ sub-results: the same step at other precisions
+    recall_bar = {}
+    rpath = os.path.join(ROOT, "profiles", "r03_recall_bar.json")
+    if os.path.exists(rpath):
+        with open(rpath) as f:
+            recall_bar = json.load(f)
     if not args.no_extras and args.precision == _lib.DEFAULT_PRECISION:
         extras = {}
         for prec in ("bf16-res16", "fp8", "fp8-res16"):
@@ -497,9 +443,15 @@ def main():
             dt = max_over_ranks(dt)
             cos = [float(torch.nn.functional.cosine_similarity(a.double(), b.double()).min()) for a, b in zip(o2, out)]
             extras[prec] = {"items_per_s": 3 * B * world * n2 / dt, "ms_per_step": 1e3 * dt / n2, "steps": n2,
-                            "min_cosine_vs_default_image_query_target": cos}
+                            "min_cosine_vs_default_image_query_target": cos, "speedup_vs_default": (3 * B * world * n2 / dt) / value,
+                            "inside_recall_bar": recall_bar.get("inside_bar_at_every_level", {}).get(prec)}
             del e2
         result["other_precisions"] = extras
+        # BASELINE configs[4] asks for fp8 encoders with Recall@10 within 0.2 % of bf16: `inside_recall_bar` is the record of the fixed-bar
+        # stress test (tests/test_encoder_gpu.py; profiles/r03_recall_bar.json) -- a speed-up of a mode outside the bar is not a
+        # config-5 result, and the mode inside it ("fp8": QKV only) buys what its line says
+        result["recall_bar"] = {"points": recall_bar.get("bar_points"), "default_precision_inside": recall_bar.get("inside_bar_at_every_level", {}).get(args.precision),
+                                "source": "profiles/r03_recall_bar.json"}
         if resadd_on:
             # the same engine with the store-only epilogues (updates applied by the LayerNorms): the GEMM class then holds GEMM
             # work only, which is the configuration the GEMM's own roofline fraction is best read on

@@ -26,8 +26,9 @@ extern "C" {
  *   "gemm_kl"       K loop of the persistent GEMM: 0 = eight 256-cycle barrier intervals per K-tile (default), 1 = four of 512
  *   "attn_v"        attention kernel at T = 257: 0 = the 16-query-tile kernel (default), 1 = 32-query tiles on v_mfma_f32_32x32x16_bf16
  *   "attn_waves"    waves per workgroup of the 16-query-tile kernel at T = 257: 0 = default (4), 6
- *   "sim_lists"     kemr_sim_topk: 0 = never the candidate-list route, 1 = where it applies (default), 2 = lists, then the
- *                   exact fallback forced */
+ *   "sim_lists"     kemr_sim_topk: 0 = never the candidate-list route (nor the fast rank pass for bonus lists), 1 = where it pays
+ *                   (default: from 2 048 gallery rows, 256 queries and 1.2e10 multiply-adds up), 3 = wherever it fits, 2 = as 3 and
+ *                   the exact fallback forced to run after the lists */
 int kemr_debug_set(const char* key, int value);
 int kemr_debug_get(const char* key, int* value);
 

@@ -656,6 +656,11 @@ static SimkLayout simk_layout(int nq, int ng, int64_t kdim, int k) {
     L.bytes = sim_lists_bytes(nq, ng, k);
     // from 2 048 gallery rows up (round 2: 8 192): an 8-way shard of the 43 000 gallery has 5 375 rows (BASELINE configs[3])
     if (k < 1 || nq < 256 || ng < 2048 || kdim % 64 != 0 || kdim < 128 || kdim > 65536) return L;
+    // ... where it pays: the route is six launches (sample pass, thresholds, list pass, selection, two fallback launches that exit
+    // at once) against sim_kernel's two, and runs at about twice sim_kernel's rate.  Measured (round 3, same device, query panel
+    // build included): 1 024 x 5 375 x 768 0.089 ms against 0.086 -- a tie; 1 024 x 43 000 0.152 against 0.361; break-even near
+    // 1.2e10 multiply-adds.  Below it sim_kernel keeps the call (debug switch sim_lists >= 2: the lists wherever they fit, tests).
+    if (g_sim_lists == 1 && (double)nq * ng * (double)kdim < 1.2e10) return L;
     // Sampled rows m: the entries >= threshold a query brings to the selection number about 1.15 k ng / m (the k-th block
     // maximum sits a little below the k-th item of the sample; measured 1.1x), Gamma(k)-distributed around that mean: the
     // smaller k, the longer the tail (k = 1: exponential).  spread(k) ~ the 1 - 1e-8 quantile over the mean (20.5 / 6.3 / 4.1 /
@@ -776,7 +781,7 @@ extern "C" int kemr_sim_topk(const void* q_panel_dev, int nq, const void* g_pane
         // the exact fallback, queued unconditionally: both kernels exit at once unless a list overflowed.  The ranks are
         // already complete (the count does not depend on the lists), so the fallback runs without a ground truth.
         p.gt_idx = nullptr; p.gt_score = nullptr; p.ahead = nullptr;
-        p.run_if = g_sim_lists == 2 ? nullptr : flag;
+        p.run_if = g_sim_lists == 2 ? nullptr : flag;          // 2: the fallback forced to run after the lists (tests); 3: lists wherever they fit
         if (k <= 10) KEMR_TRY((launch_sim<10, false>(p, s)));
         else KEMR_TRY((launch_sim<32, false>(p, s)));
         return launch_topk_merge(p.part_scores, p.part_idx, nq, p.nchunks * k, k, top_scores_dev, top_idx_dev, s, p.run_if);

@@ -298,7 +298,7 @@ def test_topk_by_candidate_lists_is_the_kernel_path_bit_for_bit(device, nq, ng, 
     sgt = engine.pair_scores(qp, gp, torch.arange(nq, device=device).int(), gt.int())
     out = {}
     try:
-        for mode in (0, 1, 2):
+        for mode in (0, 3, 2):             # sim_kernel; the lists wherever they fit (the default applies a size threshold on top); + forced fallback
             _lists_mode(mode)
             ahead = torch.zeros(nq, dtype=torch.int32, device=device)
             s_, i_ = engine.sim_topk(qp, gp, k, off, gtg, sgt, ahead)
@@ -307,9 +307,10 @@ def test_topk_by_candidate_lists_is_the_kernel_path_bit_for_bit(device, nq, ng, 
             out[mode] = (s_, i_, ahead)
     finally:
         _lists_mode(1)
-    for mode in (1, 2):
+    for mode in (3, 2):
         for a, b in zip(out[0], out[mode]):
             assert torch.equal(a, b), mode
+    out[1] = out[3]
     if ng >= 2 * 8192 + 100:
         # two shards, both on the list route, ground truths mostly in the OTHER shard: merged lists and summed counts
         cut = (ng // 2) // 7 * 7 + 3
@@ -344,7 +345,13 @@ def test_candidate_lists_overflow_falls_back_on_the_device(device):
     gt = (torch.arange(nq) % 3 + 3 * 7).int().to(device)
     sgt = engine.pair_scores(qp, gp, torch.arange(nq, device=device).int(), gt)
     ahead = torch.zeros(nq, dtype=torch.int32, device=device)
-    top_s, top_i = engine.sim_topk(qp, gp, k, 0, gt, sgt, ahead)
+    _lists_mode(3)                         # the lists wherever they fit (this small problem is below the default's size threshold)
+    try:
+        top_s, top_i, ws = engine.sim_topk(qp, gp, k, 0, gt, sgt, ahead, return_workspace=True)
+        from knowledge_enhanced_multimodal_retrieval_amd import debug
+        assert debug.sim_lists(ws, nq, ng, qp.kdim, k)[0] == 1          # the overflow flag really was raised on the device
+    finally:
+        _lists_mode(1)
     want_i = (torch.arange(nq)[:, None] % 3 + 3 * torch.arange(k)[None, :]).int().to(device)
     assert torch.equal(top_i, want_i) and torch.equal(ahead, torch.full_like(ahead, 7))
     assert bool((top_s == top_s[:, :1]).all())

@@ -23,4 +23,12 @@ if [ "$2" = "pmc" ]; then
   echo "[profile] pmc SQ (MFMA busy) on the bench step"
   rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_sq -- python3 $R/bench.py --steps 10 --warmup 0 --no-cpu-baseline --no-sim --no-extras --no-pipeline > $OUT/${TAG}_pmc_sq.log 2>&1
 fi
+if [ "$2" = "pmc" ]; then
+  echo "[profile] pmc FETCH_SIZE / WRITE_SIZE of the similarity route (Q = 43 000 top-10)"
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_sim_pmc_fetch -- python3 $R/tools/bench_sim.py --routes 1 --iters 3 > $OUT/${TAG}_sim_pmc_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_sim_pmc_write -- python3 $R/tools/bench_sim.py --routes 1 --iters 3 > $OUT/${TAG}_sim_pmc_write.log 2>&1
+  echo "[profile] summaries"
+  python3 $R/tools/pmc_summary.py "$OUT/${TAG}_pmc_*/**/*counter_collection.csv" > $OUT/${TAG}_pmc_summary.txt 2>&1 || true
+  python3 $R/tools/pmc_summary.py "$OUT/${TAG}_sim_pmc_*/**/*counter_collection.csv" > $OUT/${TAG}_sim_pmc_summary.txt 2>&1 || true
+fi
 echo "[profile] done"
