@@ -130,6 +130,7 @@ struct GemmParams {
     int32_t* sim_ahead;       // [nq] += candidates of this gallery ranked ahead of it
     int sim_ng, sim_gbase;    // valid gallery rows; global id of gallery row 0
     int sim_nchunks, sim_tpc; // gallery chunks per query tile, gallery tiles per chunk
+    int sim_xcd;              // 1: the chunks of a query tile are dealt to one XCD (gemm256u.hip, SIM prologue)
     // SIM == 2 (top-k candidates on top of the rank count): a lane whose 16 candidates of a query hold a score >= the query's
     // threshold appends all 16 scores as one record to the (query, chunk) list
     const float* simk_taud;   // [nq] next float below the threshold (s > taud  <=>  s >= threshold)

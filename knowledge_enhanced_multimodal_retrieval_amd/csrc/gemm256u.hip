@@ -255,8 +255,30 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     int ntl = (ntiles - (int)blockIdx.x + G - 1) / G;                // tiles of this workgroup, <= GEMM256U_MAX_TILES_PER_WG (host)
     int t_row = 0, t_col = 0;
     int sim_tb = 0;                                                  // SIM: first gallery tile of this workgroup's chunk
+    int sim_chunk = 0;
     if constexpr (SIM != 0) {
-        const int qt = (int)blockIdx.x / p.sim_nchunks, chunk = (int)blockIdx.x - qt * p.sim_nchunks;
+        // (query tile, gallery chunk) of this workgroup.  Round 3's FETCH_SIZE pass of the list pass read 12 GB through the fabric
+        // per launch at Q = N = 43 000 for 0.13 GB of operands: a workgroup re-reads its 393 KB query tile for every gallery tile,
+        // and with blockIdx = tile * chunks + chunk the 32 workgroups an XCD holds at a time own ~11 different query tiles -- 12 MB
+        // of A against a 4 MiB L2, so every re-read goes to the Infinity Cache.  Now the workgroups of ONE query tile (its chunks)
+        // are dealt to ONE XCD (blocks with equal blockIdx % 8 share an XCD: observed placement, speed only), back to back, so
+        // that they start together, walk their gallery tiles in step and share every re-read of the query tile in that XCD's
+        // L2; the ~10 workgroups of an XCD that sit on the same chunk share its gallery tiles as before.  The grid is padded to
+        // whole groups of 8 query tiles; a workgroup of a tile that does not exist returns before its first barrier.
+        // (Few query tiles -- fewer than 64, not a multiple of 8 -- keep blockIdx = tile * chunks + chunk: Q = 1 024 is 4 tiles, which
+        // this dealing would put on 4 of the 8 XCDs: 0.15 -> 0.21 ms.)
+        int qt, chunk;
+        if (p.sim_xcd) {
+            const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+            const int jq = j / p.sim_nchunks;
+            chunk = j - jq * p.sim_nchunks;
+            qt = jq * 8 + xcd;
+            if ((qt << 8) >= p.M) return;
+        } else {
+            qt = (int)blockIdx.x / p.sim_nchunks;
+            chunk = (int)blockIdx.x - qt * p.sim_nchunks;
+        }
+        sim_chunk = chunk;
         sim_tb = chunk * p.sim_tpc;
         const int te = min(sim_tb + p.sim_tpc, tiles_n);
         ntl = te - sim_tb;
@@ -780,7 +802,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             }
             if constexpr (SIM == 2) {
                 if (__builtin_amdgcn_ballot_w64(hitmask != 0u) != 0) {
-                    const int chunk = (int)blockIdx.x - ((int)blockIdx.x / p.sim_nchunks) * p.sim_nchunks;
+                    const int chunk = sim_chunk;
 #pragma unroll
                     for (int mi = 0; mi < 8; ++mi) {
                         if ((hitmask >> mi) & 1u) {
@@ -1039,7 +1061,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (tid < 256 && t_row_u + tid < p.M) {
-            const int chunk = (int)blockIdx.x - ((int)blockIdx.x / p.sim_nchunks) * p.sim_nchunks;
+            const int chunk = sim_chunk;
             const int n = *(volatile int*)(smem + PEPI + 4096 + tid * 4);
             p.simk_count[(size_t)(t_row_u + tid) * p.sim_nchunks + chunk] = min(n, p.simk_cap);
         }
@@ -1164,7 +1186,9 @@ static int launch_sim_mode_a(const GemmParams& p, int q_tiles, hipStream_t strea
         KEMR_CHECK_HIP(hipGetSymbolAddress((void**)&q.stamps, HIP_SYMBOL(g_gemm_stamp_buf)));
     }
     ProfScope prof(PROF_SIM, stream);
-    hipLaunchKernelGGL(kern, dim3(q_tiles * p.sim_nchunks), dim3(512), PSMEM, stream, q);
+    q.sim_xcd = (q_tiles % 8 == 0 || q_tiles >= 64) ? 1 : 0;
+    const int grid_q = q.sim_xcd ? ((q_tiles + 7) / 8) * 8 : q_tiles;      // XCD dealing: whole groups of 8 query tiles (one per XCD)
+    hipLaunchKernelGGL(kern, dim3(grid_q * p.sim_nchunks), dim3(512), PSMEM, stream, q);
     KEMR_CHECK_LAUNCH("gemm256u_bf16_nt_kernel<sim>");
     return KEMR_OK;
 }

@@ -434,11 +434,12 @@ def test_attention_257_both_kernels_and_exact_structure(device, batch, width):
     qkv_bf = qkv.to(torch.bfloat16)
     ref = _attention_ref(qkv_bf, batch, t, width, False)
     outs = {}
-    for v in (0, 1):
+    for v in (0, 1, 2):
         with debug.override(attn_v=v):
             outs[v] = engine.op_attention(qkv_bf.to(device), batch, t, width, False).float().cpu()
         assert float((outs[v] - ref).abs().max()) < 3e-2 and float((outs[v] - ref).abs().mean()) < 3e-3, v
     assert float((outs[0] - outs[1]).abs().max()) < 2e-2
+    assert torch.equal(outs[0], outs[2])              # the interleaved form is the same arithmetic in the same order
     # one-hot: query i of head hd looks for key perm[i]: q = 64 * e_(c(i)), k_j = e_(c'(j)) built so that q_i . k_j = 64 iff j == perm[i]
     heads = width // 64
     perm = torch.randperm(t, generator=g)
@@ -461,7 +462,7 @@ def test_attention_257_both_kernels_and_exact_structure(device, batch, width):
     want = torch.empty(batch * t, width)
     for b in range(batch):
         want[b * t:(b + 1) * t] = vals[b * t:(b + 1) * t][perm]
-    for v in (0, 1):
+    for v in (0, 1, 2):
         with debug.override(attn_v=v):
             got = engine.op_attention(xb.to(device), batch, t, width, False).float().cpu()
         assert float((got - want).abs().max()) < 1e-6, (v, float((got - want).abs().max()))
