@@ -29,11 +29,7 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
 // TC > 0: the sequence length is a compile-time constant (257 / 77: the shapes that matter), so every pad-key mask and
 // tile-skip test folds away; TC == 0 keeps T a run-time value (other models, tests).  With a run-time T the uniform
 // conditions of the 18 unrolled tiles overflowed the SGPR file (150+ v_readlane/v_writelane spills per query tile).
-// FUSE (round 3): the same arithmetic with the phases of a tile interleaved instead of fenced -- the key mask and the row maximum of
-// key-tile group g - 1 ride behind the MFMAs of group g, and a 32-key block's exponentials, row-sum terms and bf16 packing sit in
-// the PV loop right in front of the four MFMAs that consume them, so that the compiler can run the VALU work of block u + 1 beside
-// the MFMAs of block u (round 2's PMC: a wave spends a third of its cycles issue-stalled on exactly these phase boundaries).
-template <int NT32, bool CAUSAL, int TC, int NW = 4, bool FUSE = false>   // keys padded to NT32 * 32; NW waves per workgroup
+template <int NT32, bool CAUSAL, int TC, int NW = 4>   // keys padded to NT32 * 32; NW waves per workgroup
 __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            int T_rt, int width) {
     const int T = TC > 0 ? TC : T_rt;
@@ -117,8 +113,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
                 for (int kk = 0; kk < 2; ++kk)
                     dst[j][kk] = *(const bf16x8*)(sK + ((g * G + j) * 16 + lrow) * 128 + (((kk * 4 + lq) ^ (lrow >> 1)) << 4));
         };
+        load_group(0, kfr[0]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG && (g + 1) * G * 16 < T) load_group(g + 1, kfr[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int t = g * G + j;
+                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (t * 16 < T && (!CAUSAL || t <= qt)) {      // tiles made only of pad keys -- or, causal, of keys behind the query tile -- are skipped (uniform); the mask below covers them
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[g & 1][j][0], qf[0], s[t], 0, 0, 0);
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[g & 1][j][1], qf[1], s[t], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // s[t][r] = S[query lrow][key t*16 + lq*4 + r]
         float mx = -INFINITY;
-        auto mask_max = [&](int t) {                           // s[t][r] = S[query lrow][key t*16 + lq*4 + r]
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) {
             const bool partial = (t + 1) * 16 > T || CAUSAL;   // only the boundary tiles (or causal) need a mask
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -129,36 +143,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
                 }
                 mx = fmaxf(mx, s[t][r]);
             }
-        };
-        load_group(0, kfr[0]);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG && (g + 1) * G * 16 < T) load_group(g + 1, kfr[(g + 1) & 1]);
-            if constexpr (!FUSE) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < G; ++j) {
-                const int t = g * G + j;
-                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (t * 16 < T && (!CAUSAL || t <= qt)) {      // tiles made only of pad keys -- or, causal, of keys behind the query tile -- are skipped (uniform); the mask below covers them
-                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[g & 1][j][0], qf[0], s[t], 0, 0, 0);
-                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[g & 1][j][1], qf[1], s[t], 0, 0, 0);
-                }
-            }
-            if constexpr (FUSE) {                              // the previous group's scores have left the matrix pipe by now
-                if (g > 0) {
-#pragma unroll
-                    for (int j = 0; j < G; ++j) mask_max((g - 1) * G + j);
-                }
-            } else {
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if constexpr (FUSE) {
-#pragma unroll
-            for (int j = 0; j < G; ++j) mask_max((NG - 1) * G + j);
-        } else {
-#pragma unroll
-            for (int t = 0; t < NT16; ++t) mask_max(t);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -167,18 +151,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
         // instruction (v_pk_fma_f32 / v_pk_add_f32): the softmax is issue-bound, the MFMAs hide behind it
         f32x2_t sum2 = {0.f, 0.f};
         const f32x2_t l2 = {LOG2E, LOG2E}, nm = {-mxl, -mxl};
-        auto exp_tile = [&](int t) {
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) {
             f32x2_t a = f32x2_t{s[t][0], s[t][1]} * l2 + nm, c = f32x2_t{s[t][2], s[t][3]} * l2 + nm;
             a.x = __builtin_amdgcn_exp2f(a.x); a.y = __builtin_amdgcn_exp2f(a.y);
             c.x = __builtin_amdgcn_exp2f(c.x); c.y = __builtin_amdgcn_exp2f(c.y);
             s[t][0] = a.x; s[t][1] = a.y; s[t][2] = c.x; s[t][3] = c.y;
             sum2 += a;
             sum2 += c;
-        };
-        if constexpr (!FUSE) {
-#pragma unroll
-            for (int t = 0; t < NT16; ++t) exp_tile(t);
         }
+        float sum = sum2.x + sum2.y;
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
 
         f32x4 o[4];
 #pragma unroll
@@ -202,8 +186,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
         for (int u = 0; u < NT32; ++u) {
             if (u * 32 >= T || (CAUSAL && u * 32 > qt * 16 + 15)) continue;      // all-pad key block, or all behind the diagonal: P = 0 (uniform)
             if (u + 1 < NT32 && (u + 1) * 32 < T) load_v(u + 1, vfr[(u + 1) & 1]);
-            if constexpr (FUSE) { exp_tile(2 * u); exp_tile(2 * u + 1); }
-            else __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
             union { bf16x8 v; uint32_t w[4]; } pf;
             pf.w[0] = pack_bf16x2(s[2 * u][0], s[2 * u][1]);
             pf.w[1] = pack_bf16x2(s[2 * u][2], s[2 * u][3]);
@@ -212,11 +195,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[u & 1][dt], pf.v, o[dt], 0, 0, 0);
-            if constexpr (!FUSE) __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        float sum = sum2.x + sum2.y;
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
         // o[dt][r] = O[query lrow][d = dt*16 + lq*4 + r]
         if (q < T) {
             const float inv = 1.0f / sum;
@@ -416,7 +396,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attention32_kernel(const bf16_t* _
 // work, yet its waves spend 43 % of their cycles issue-stalled (SQ_WAIT_INST_ANY) where the 16-query kernel's spend 32 %: with 1.4
 // waves per SIMD on average neither hides the MFMA -> VALU -> MFMA dependence of a tile (S^T, softmax, PV), and the longer 32 x 32
 // chains expose more of it.  What is missing is a second tile in flight per wave, not fewer instructions.  Kept behind the
-// debug switch attn_v = 1 with its tests; the default stays the 16-query kernel.
+// debug switch attn_v = 1 with its tests; the default stays the 16-query kernel.  (Also tried on the 16-query kernel and dropped: the
+// fences between its phases removed, mask + row maximum of key group g - 1 behind the MFMAs of group g, each 32-key block's
+// exponentials in the PV loop in front of the MFMAs that consume them -- hipcc hoists the exponentials, the kernel reaches 256
+// VGPRs with 28 bytes of scratch and takes 199-208 us against 178-184 on the same device.  A second tile in flight needs the
+// schedule written by hand, as the GEMM's is.)
 int g_attn_v = 0;          // tools: 0 = the 16-query-tile kernel (default), 1 = 32-query tiles on the 32x32x16 MFMA at T = 257
 
 int g_attn_waves = 0;      // tools: 0 = the default choice below, else waves per workgroup for the 257-token shape (4 or 6)
@@ -429,8 +413,7 @@ static int launch_nt(const bf16_t* qkv, bf16_t* out, int batch, int t, int width
     void (*kern)(const bf16_t*, bf16_t*, int, int);
     int threads = 256;
     if (causal) {
-        if (NT32 == 3 && t == 77 && g_attn_v == 2) { kern = attention_kernel<NT32, true, NT32 == 3 ? 77 : 0, NT32 == 3 ? 5 : 4, true>; threads = 320; }
-        else if (NT32 == 3 && t == 77) { kern = attention_kernel<NT32, true, NT32 == 3 ? 77 : 0, NT32 == 3 ? 5 : 4>; threads = 320; }
+        if (NT32 == 3 && t == 77) { kern = attention_kernel<NT32, true, NT32 == 3 ? 77 : 0, NT32 == 3 ? 5 : 4>; threads = 320; }
         else kern = attention_kernel<NT32, true, 0>;
     } else if (NT32 == 9 && t == 257 && g_attn_v == 1) {
         auto k32 = attention32_kernel<4>;
@@ -439,8 +422,7 @@ static int launch_nt(const bf16_t* qkv, bf16_t* out, int batch, int t, int width
         KEMR_CHECK_LAUNCH("attention32_kernel");
         return KEMR_OK;
     } else if (NT32 == 9 && t == 257) {
-        if (g_attn_v == 2) kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, 4, true>;
-        else if (g_attn_waves == 6) { kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, NT32 == 9 ? 6 : 4>; threads = 384; }
+        if (g_attn_waves == 6) { kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, NT32 == 9 ? 6 : 4>; threads = 384; }
         else kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0>;
     } else {
         kern = attention_kernel<NT32, false, 0>;
