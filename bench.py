@@ -413,7 +413,13 @@ def main():
                                   "flops": 2.0 * GALLERY * GALLERY * arch.embed_dim, "ms": hs["ms"],
                                   "achieved": hs["mfma_tflops_per_gpu"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                   "frac": hs["mfma_tflops_per_gpu"] / PEAK_BF16_TFLOPS,
-                                  "min_bytes": 2 * GALLERY * arch.embed_dim * 2 + GALLERY * 10 * 8}
+                                  "min_bytes": 2 * GALLERY * arch.embed_dim * 2 + GALLERY * 10 * 8, "traffic": None}
+        spath = os.path.join(ROOT, "profiles", "sim_traffic.json")
+        if os.path.exists(spath) and world == 1 and args.model == "ViT-L/14":      # measured for this exact call (separate --pmc passes)
+            with open(spath) as f:
+                sj = json.load(f)
+            result["roofline_sim"]["traffic"] = sj.get("bytes_per_launch")
+            result["roofline_sim"]["traffic_source"] = {k: sj.get(k) for k in ("kernel", "profile", "round", "commit", "method")}
 
     # ------------------------------------------------------------------ sub-results: the same step at other precisions
     recall_bar = {}
