@@ -24,8 +24,12 @@ extern "C" {
  *   "gemm_order"    tile order of the persistent GEMM: 0 = N fastest, else log2(column-group width) + 1 (default 3)
  *   "gemm_conc"     both wave halves' epilogues in one barrier interval: 0 never, 1 always, 2 = QuickGELU epilogue only (default)
  *   "gemm_kl"       K loop of the persistent GEMM: 0 = eight 256-cycle barrier intervals per K-tile (default), 1 = four of 512
- *   "attn_v"        attention kernel at T = 257: 0 = the 16-query-tile kernel (default), 1 = 32-query tiles on v_mfma_f32_32x32x16_bf16
- *   "attn_waves"    waves per workgroup of the 16-query-tile kernel at T = 257: 0 = default (4), 6
+ *   "attn_v"        attention kernel at T = 257: 0 = the 16-query-tile kernel, 4 waves (default), 1 = 32-query tiles on
+ *                   v_mfma_f32_32x32x16_bf16, 2 = eight waves per workgroup with the keys in two halves (online softmax),
+ *                   3 = as 2, one persistent workgroup per CU, the next head's K / V by LDS-DMA while this one is computed
+ *   "attn_xcd"      attention: 1 = XCD x computes the images = x (mod 8), the heads of an image next to each other in time
+ *                   (default), 0 = grid order
+ *   "attn_waves"    waves per workgroup at T = 257: 0 = default (4 for attn_v 0, 16 for attn_v 3), 6 (attn_v 0), 8 (attn_v 3)
  *   "sim_lists"     kemr_sim_topk: 0 = never the candidate-list route (nor the fast rank pass for bonus lists), 1 = where it pays
  *                   (default: from 2 048 gallery rows, 256 queries and 1.2e10 multiply-adds up), 3 = wherever it fits, 2 = as 3 and
  *                   the exact fallback forced to run after the lists */

@@ -143,6 +143,7 @@ struct GemmParams {
 extern int g_gemm_dbg;
 extern int g_gemm_order;
 extern int g_sim_lists;     // sim.hip: candidate-list route of kemr_sim_topk (kemr_debug_set "sim_lists")
+extern int g_attn_xcd;      // attention.hip (tools)
 extern int g_attn_waves;    // attention.hip (tools)
 extern int g_attn_v;        // attention.hip (tools): 1 = 32-query tiles on the 32x32x16 MFMA at T = 257
 extern int g_gemm_kl;       // gemm256u: 1 = long-interval K loop (round 3, default), 0 = round 2's (tools/ A/B)

@@ -11,7 +11,7 @@ import ctypes as C
 
 from . import _lib
 
-KEYS = ("gemm_variant", "gemm_flags", "gemm_order", "gemm_conc", "gemm_kl", "attn_v", "attn_waves", "sim_lists")
+KEYS = ("gemm_variant", "gemm_flags", "gemm_order", "gemm_conc", "gemm_kl", "attn_v", "attn_xcd", "attn_waves", "sim_lists")
 
 
 def set(key: str, value: int) -> None:      # noqa: A001 (module-level verb of a tiny module)

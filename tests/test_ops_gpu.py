@@ -434,12 +434,14 @@ def test_attention_257_both_kernels_and_exact_structure(device, batch, width):
     qkv_bf = qkv.to(torch.bfloat16)
     ref = _attention_ref(qkv_bf, batch, t, width, False)
     outs = {}
-    for v in (0, 1, 2):
+    for v in (0, 1, 2, 3):
         with debug.override(attn_v=v):
             outs[v] = engine.op_attention(qkv_bf.to(device), batch, t, width, False).float().cpu()
         assert float((outs[v] - ref).abs().max()) < 3e-2 and float((outs[v] - ref).abs().mean()) < 3e-3, v
     assert float((outs[0] - outs[1]).abs().max()) < 2e-2
-    assert torch.equal(outs[0], outs[2])              # the interleaved form is the same arithmetic in the same order
+    for v in (0, 2):                                      # grid order instead of the images dealt to the XCDs (the default): another
+        with debug.override(attn_v=v, attn_xcd=0):        # workgroup numbering, the same results
+            assert torch.equal(engine.op_attention(qkv_bf.to(device), batch, t, width, False).float().cpu(), outs[v]), v
     # one-hot: query i of head hd looks for key perm[i]: q = 64 * e_(c(i)), k_j = e_(c'(j)) built so that q_i . k_j = 64 iff j == perm[i]
     heads = width // 64
     perm = torch.randperm(t, generator=g)
@@ -462,8 +464,87 @@ def test_attention_257_both_kernels_and_exact_structure(device, batch, width):
     want = torch.empty(batch * t, width)
     for b in range(batch):
         want[b * t:(b + 1) * t] = vals[b * t:(b + 1) * t][perm]
-    for v in (0, 1, 2):
+    for v in (0, 1, 2, 3):
         with debug.override(attn_v=v):
             got = engine.op_attention(xb.to(device), batch, t, width, False).float().cpu()
         assert float((got - want).abs().max()) < 1e-6, (v, float((got - want).abs().max()))
 
+
+@pytest.mark.parametrize("spike_key", [3, 150, 200, 256])
+def test_attention_257_online_softmax_rescale_is_exercised(device, spike_key):
+    """attn_v = 2 takes a tile's keys in two halves (tiles 0-9 and 10-17) with a running maximum: one key far ahead of the rest,
+    in the FIRST half (the second half must not disturb it), in the SECOND half (o and l of the first half are rescaled by
+    exp(m_old - m_new) ~ e^-30), at the seam, and as the lone 257th key -- against the fp32 torch statement over the FULL tensor, and
+    against the single-pass kernel (cdna guide rule 26: a rare rescale branch needs an input that forces it)."""
+    from knowledge_enhanced_multimodal_retrieval_amd import debug
+    t, batch, width = 257, 2, 256
+    g = torch.Generator().manual_seed(spike_key)
+    qkv = torch.randn(batch * t, 3 * width, generator=g) * 0.3
+    qkv[:, 0] = 6.0                                       # q[:, d0] = 6 for head 0, every query
+    for b in range(batch):
+        qkv[b * t + spike_key, width] = 5.0               # k[spike, d0] = 5: logit 30 ahead of the rest
+        qkv[b * t + (spike_key + 100) % t, width] = 2.5   # a runner-up in the other half: logit 15
+    qkv_bf = qkv.to(torch.bfloat16)
+    ref = _attention_ref(qkv_bf, batch, t, width, False)
+    outs = {}
+    for v in (0, 2, 3):
+        with debug.override(attn_v=v):
+            outs[v] = engine.op_attention(qkv_bf.to(device), batch, t, width, False).float().cpu()
+        assert torch.isfinite(outs[v]).all()
+        assert float((outs[v] - ref).abs().max()) < 3e-2, (v, float((outs[v] - ref).abs().max()))
+    assert float((outs[0] - outs[2]).abs().max()) < 2e-2
+    assert float((outs[2] - outs[3]).abs().max()) < 4e-3   # the persistent form: the same arithmetic per head up to hipcc's contraction
+
+
+
+@pytest.mark.gpu
+def test_attention_257_persistent_kernel_walks_several_items(device):
+    """attn_v = 3: one workgroup per CU walks a list of (image, head) items, the K / V rows of the next one arriving by LDS-DMA in
+    the other buffer while the tiles of the current one run.  100 images x 8 heads = 800 items over 256 workgroups: up to four
+    items per workgroup (both buffers reused), XCDs with 13 and with 12 images (100 = 12 * 8 + 4) -- against the one-item-per-
+    workgroup kernel with the same arithmetic (bit-identical) and against the fp32 torch statement on a sample of the images."""
+    from knowledge_enhanced_multimodal_retrieval_amd import debug
+    t, batch, width = 257, 100, 512
+    g = torch.Generator().manual_seed(11)
+    qkv_bf = (torch.randn(batch * t, 3 * width, generator=g) * 0.7).to(torch.bfloat16)
+    x = qkv_bf.to(device)
+    with debug.override(attn_v=2):
+        one_item = engine.op_attention(x, batch, t, width, False)
+    outs = {}
+    for waves in (0, 8):                                  # 16 waves, one tile each (the default of attn_v = 3) / 8 waves, two tiles each
+        with debug.override(attn_v=3, attn_waves=waves):
+            outs[waves] = engine.op_attention(x, batch, t, width, False)
+            again = engine.op_attention(x, batch, t, width, False)
+        torch.cuda.synchronize()
+        assert torch.equal(again, outs[waves])            # nothing left over in LDS, no dependence on the previous launch
+        # the same source arithmetic per head as the one-item kernel, compiled in another context (hipcc contracts a*b+c differently:
+        # 1 element of 13 M off by one bf16 ulp on the round-3 device): equal up to rounding, not bit for bit
+        d = (outs[waves].float() - one_item.float()).abs()
+        assert float(d.max()) < 4e-3 and int((d > 0).sum()) < 1e-5 * d.numel(), (waves, float(d.max()), int((d > 0).sum()))
+    pick = [0, 7, 8, 63, 95, 96, 99]                      # first / last image of an XCD's list, the ragged tail
+    rows = torch.cat([torch.arange(b * t, (b + 1) * t) for b in pick])
+    ref = _attention_ref(qkv_bf[rows], len(pick), t, width, False)
+    for waves in (0, 8):
+        got = outs[waves].float().cpu()[rows]
+        assert float((got - ref).abs().max()) < 3e-2 and float((got - ref).abs().mean()) < 3e-3, waves
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t,causal,batch,width", [(77, True, 19, 192), (257, False, 19, 192), (50, False, 9, 128), (257, False, 1, 1024)])
+def test_attention_images_dealt_to_the_xcds(device, t, causal, batch, width):
+    """The default numbering of the attention workgroups (XCD x takes the images = x mod 8; a grid of heads x batch rounded up to 8
+    whose surplus workgroups leave at once) against grid order: bit-identical, for batches that are not multiples of 8, head counts
+    that are not powers of two and a single image; and against the fp32 torch statement."""
+    from knowledge_enhanced_multimodal_retrieval_amd import debug
+    g = torch.Generator().manual_seed(batch * 1000 + t)
+    qkv = torch.randn(batch * t, 3 * width, generator=g)
+    qkv[:, :width] *= 0.25
+    qkv_bf = qkv.to(torch.bfloat16)
+    x = qkv_bf.to(device)
+    assert debug.get("attn_xcd") == 1
+    dealt = engine.op_attention(x, batch, t, width, causal)
+    with debug.override(attn_xcd=0):
+        plain = engine.op_attention(x, batch, t, width, causal)
+    assert torch.equal(dealt, plain)
+    ref = _attention_ref(qkv_bf, batch, t, width, causal)
+    assert float((dealt.float().cpu() - ref).abs().max()) < 3e-2

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The vision attention launch (B = 255, T = 257, 16 heads) a few times, for rocprofv3 --pmc / --kernel-trace.
-argv: attn_v (0 = the 16-query-tile kernel, 1 = 32-query tiles on the 32x32x16 MFMA) [debug]: with `debug`, the one-hot exact test
+argv: attn_v (0 = the 16-query-tile kernel, 1 = 32-query tiles on the 32x32x16 MFMA, 2 = eight waves, keys in two halves) [debug]: with `debug`, the one-hot exact test
 of tests/test_ops_gpu.py and the list of (batch, head, query) rows that differ."""
 import os
 import sys
@@ -12,7 +12,10 @@ from knowledge_enhanced_multimodal_retrieval_amd import debug, engine  # noqa: E
 
 dev = torch.device("cuda:0")
 v = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-debug.set("attn_v", v)
+debug.set("attn_v", v % 10)
+debug.set("attn_xcd", (v // 10) % 10)
+debug.set("attn_waves", v // 100)
+_=(0)                # 10, 12: the same kernels with the images dealt to the XCDs
 if len(sys.argv) > 2 and sys.argv[2] == "debug":
     t, batch, width = 257, 2, 256
     g = torch.Generator().manual_seed(3)
@@ -41,15 +44,15 @@ if len(sys.argv) > 2 and sys.argv[2] == "debug":
         match = [(j, float((vv[j] - gq).abs().max())) for j in range(t) if float((vv[j] - gq).abs().max()) < 0.51]
         print("  row", (b, h, q), "target", tk, "closest V rows:", match[:4], "got[:6]", gq[:6].tolist(), "want[:6]", want.view(batch, t, heads, 64)[b, q, h][:6].tolist())
     sys.exit(0)
-B = 255
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 255
 g = torch.Generator(device=dev).manual_seed(0)
 qkv = (torch.randn(B * 257, 3072, generator=g, device=dev) * 0.5).to(torch.bfloat16)
-for _ in range(6):
+for _ in range(300):
     engine.op_attention(qkv, B, 257, 1024, False)
 torch.cuda.synchronize()
 t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
 t0.record()
-for _ in range(10):
+for _ in range(300):
     engine.op_attention(qkv, B, 257, 1024, False)
 t1.record(); torch.cuda.synchronize()
-print("attention T=257 B=255 attn_v=%d: %.1f us" % (v, t0.elapsed_time(t1) * 100))
+print("attention T=257 B=%d attn_v=%d: %.1f us" % (B, v, t0.elapsed_time(t1) / 300 * 1e3))
