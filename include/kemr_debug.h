@@ -29,7 +29,9 @@ extern "C" {
  *                   3 = as 2, one persistent workgroup per CU, the next head's K / V by LDS-DMA while this one is computed
  *   "attn_xcd"      attention: 1 = XCD x computes the images = x (mod 8), the heads of an image next to each other in time
  *                   (default), 0 = grid order
- *   "attn_waves"    waves per workgroup at T = 257: 0 = default (4 for attn_v 0, 16 for attn_v 3), 6 (attn_v 0), 8 (attn_v 3)
+ *   "attn_waves"    waves per workgroup at T = 257: 0 = default (4 for attn_v 0, 16 for attn_v 3), 6 (attn_v 0), 8 (attn_v 3);
+ *                   2 (attn_v 0) = the build with s_memtime stamps, which writes 8 counters per wave BEHIND the output
+ *                   (tools/prof_attention.py allocates the room; nothing else may select it)
  *   "sim_lists"     kemr_sim_topk: 0 = never the candidate-list route (nor the fast rank pass for bonus lists), 1 = where it pays
  *                   (default: from 2 048 gallery rows, 256 queries and 1.2e10 multiply-adds up), 3 = wherever it fits, 2 = as 3 and
  *                   the exact fallback forced to run after the lists */

@@ -43,7 +43,7 @@ __device__ __forceinline__ bool attn_item(int xbatch, int& h, int& b) {
     return b < xbatch;
 }
 
-template <int NT32, bool CAUSAL, int TC, int NW = 4>   // keys padded to NT32 * 32; NW waves per workgroup
+template <int NT32, bool CAUSAL, int TC, int NW = 4, bool STAMP = false>   // keys padded to NT32 * 32; NW waves per workgroup
 __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            int T_rt, int width, int xbatch) {
     const int T = TC > 0 ? TC : T_rt;
@@ -65,6 +65,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
     const int lrow = lane & 15, lq = lane >> 4;
     const int nqt = (T + 15) >> 4;
 
+    unsigned long long st_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
+    auto stamp = [&](int k) {
+        if constexpr (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long now;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            st_t[k] += now - st_prev;
+            st_prev = now;
+        }
+    };
+    if constexpr (STAMP) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
     // first query tile of this wave: issue its loads before the K/V staging so that their latency overlaps it
     bf16x8 qn[2];
     {
@@ -103,6 +115,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
         }
     }
     __syncthreads();
+    stamp(0);                                           // staging (loads, LDS writes, barrier)
 
     for (int qt = wid; qt < nqt; qt += NW) {           // wave-uniform trip count: EXEC stays full for the tr reads
         const int q = qt * 16 + lrow;
@@ -144,6 +157,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        stamp(1);                                       // S^T MFMAs + K reads (+ the wait for this tile's Q)
         // s[t][r] = S[query lrow][key t*16 + lq*4 + r]
         float mx = -INFINITY;
 #pragma unroll
@@ -162,23 +176,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float mxl = mx * LOG2E;
+        stamp(2);                                       // mask + row max + exchange
         // exp(s - max) = exp2(s * log2e - max * log2e); masked keys -> 0.  The multiply-add and the row sum run two elements per
         // instruction (v_pk_fma_f32 / v_pk_add_f32): the softmax is issue-bound, the MFMAs hide behind it
         f32x2_t sum2 = {0.f, 0.f};
         const f32x2_t l2 = {LOG2E, LOG2E}, nm = {-mxl, -mxl};
-#pragma unroll
-        for (int t = 0; t < NT16; ++t) {
+        auto exp_tile = [&](int t) {
             f32x2_t a = f32x2_t{s[t][0], s[t][1]} * l2 + nm, c = f32x2_t{s[t][2], s[t][3]} * l2 + nm;
             a.x = __builtin_amdgcn_exp2f(a.x); a.y = __builtin_amdgcn_exp2f(a.y);
             c.x = __builtin_amdgcn_exp2f(c.x); c.y = __builtin_amdgcn_exp2f(c.y);
             s[t][0] = a.x; s[t][1] = a.y; s[t][2] = c.x; s[t][3] = c.y;
             sum2 += a;
             sum2 += c;
-        }
-        float sum = sum2.x + sum2.y;
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
+        };
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) exp_tile(t);
 
+        stamp(3);                                       // exponentials + row sum
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -197,9 +211,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
             }
         };
         load_v(0, vfr[0]);
+        // a block that is all pad keys, or (causal) all behind the diagonal, has P = 0 and is skipped (uniform); the live blocks are a prefix
+        auto live = [&](int u) { return u < NT32 && u * 32 < T && !(CAUSAL && u * 32 > qt * 16 + 15); };
 #pragma unroll
         for (int u = 0; u < NT32; ++u) {
-            if (u * 32 >= T || (CAUSAL && u * 32 > qt * 16 + 15)) continue;      // all-pad key block, or all behind the diagonal: P = 0 (uniform)
+            if (!live(u)) continue;
             if (u + 1 < NT32 && (u + 1) * 32 < T) load_v(u + 1, vfr[(u + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
             union { bf16x8 v; uint32_t w[4]; } pf;
@@ -212,6 +228,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[u & 1][dt], pf.v, o[dt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        stamp(4);                                       // PV MFMAs + V reads + P packing
+        float sum = sum2.x + sum2.y;
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
         // o[dt][r] = O[query lrow][d = dt*16 + lq*4 + r]
         if (q < T) {
             const float inv = 1.0f / sum;
@@ -223,6 +243,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
                 pk.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
                 *(uint2*)(dst + dt * 16) = pk;
             }
+        }
+        stamp(5);                                       // normalise + store
+    }
+    if constexpr (STAMP) {                              // behind the output: 8 counters of wave-cycles (tools/prof_attention.py stamps)
+        unsigned long long* dst = (unsigned long long*)(out + (size_t)xbatch * T * width) + (((size_t)b * (width >> 6) + h) * NW + wid) * 8;
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dst[k] += st_t[k];
+            dst[6] += 1;
         }
     }
 }
@@ -647,9 +676,18 @@ __global__ __launch_bounds__(512, 4) void attention_w8_kernel(const bf16_t* __re
 // 1 070 of them; PMC: SQ_ACTIVE_INST_VALU = 33 % of the launch) + 1 120 cycles of MFMA (70 x 16; SQ_VALU_MFMA_BUSY_CYCLES = 21 %)
 // + LDS waits -- not their maximum: within a wave S^T -> softmax -> PV is a dependence chain, and the waves of a SIMD, which all run
 // that same chain, overlap their MFMA and VALU phases only by accident (a persistent workgroup, whose waves leave a barrier
-// together, least of all: hence 168).  The floor with the two pipes overlapped is ~1 800 cycles per tile, ~60 us per launch; reaching
-// for it means issuing the MFMAs of key block j + 1 between the exponentials of block j in ONE instruction stream, which hipcc
-// undoes (the FUSE note further down): a hand-scheduled loop like the GEMM's.  Kept behind attn_v = 3 with its tests.
+// together, least of all: hence 168).  s_memtime stamps between the phases of the 16-query kernel (tools/prof_attention.py 10 stamps;
+// the instrumented build runs at the speed of the plain one) split a wave's life into 28 % staging (idle), 24 % S^T + K reads
+// (1 760 ticks per tile for 580 cycles of MFMA), 7 % mask + max, 14.5 % exponentials (1 050 per tile = 67 x 16: issue-bound), 19 %
+// PV + V reads (1 370 per tile for 580 of MFMA), 7 % normalise + store; 30.8 k ticks per wave in 18.7 us say the clock sits near
+// 1.65 GHz in this kernel.  At that clock the tiles of a launch cost 120 us of VALU + MFMA issue per SIMD (no overlap) and 92 us of
+// LDS reads per CU (71.7 KB per tile at 128 B / clk; eight waves share one LDS): the tile phases run within ~10 % of both, i.e. the
+// kernel is near the limit of THIS shape of the work, and a faster one has to change the shape: K / V fragments shared by two
+// query tiles (half the LDS bytes) AND the two pipes overlapped inside one instruction stream (max(1 800, 1 120) instead of their
+// sum) AND the staging hidden -- each alone was tried and bought nothing or lost (attention32, the persistent kernel, and, on the
+// 16-query kernel: the exponentials of block u + 1 pinned between the PV MFMAs of block u with sched_group_barrier: 152 us
+// against 150, bit-identical; the next round's rows touched ahead into L2 by 4-byte LDS-DMA: staging 8.7 k -> 6.7 k ticks but
+// 164 us).  Kept behind attn_v = 3 with its tests.
 #define KEMR_ATTN_GLDS(VOFF, SBASE, LDSADDR) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" \
                                                           :: "v"(VOFF), "s"(SBASE), "s"(LDSADDR) : "memory")
 template <int NW>                                       // waves per workgroup: 8 (two tiles each) or 16 (one tile each, <= 128 VGPRs)
@@ -799,6 +837,8 @@ static int launch_nt(const bf16_t* qkv, bf16_t* out, int batch, int t, int width
         return KEMR_OK;
     } else if (NT32 == 9 && t == 257) {
         if (g_attn_waves == 6) { kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, NT32 == 9 ? 6 : 4>; threads = 384; }
+        else if (g_attn_waves == 2 && xbatch) kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, 4, NT32 == 9>;   // stamps: the caller's
+                                                                                                                         // `out` has room behind it
         else kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0>;
     } else {
         kern = attention_kernel<NT32, false, 0>;

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """The vision attention launch (B = 255, T = 257, 16 heads) a few times, for rocprofv3 --pmc / --kernel-trace.
-argv: attn_v (0 = the 16-query-tile kernel, 1 = 32-query tiles on the 32x32x16 MFMA, 2 = eight waves, keys in two halves) [debug]: with `debug`, the one-hot exact test
-of tests/test_ops_gpu.py and the list of (batch, head, query) rows that differ."""
+argv[1]: a number whose units digit is attn_v (0 = the 16-query-tile kernel, 1 = 32-query tiles on the 32x32x16 MFMA, 2 = eight
+waves / keys in two halves, 3 = the persistent LDS-DMA kernel), tens digit attn_xcd (1 = the images dealt to the XCDs, the library's
+default; 0 = grid order) and hundreds attn_waves -- "10" is the product kernel.  argv[2]: a batch size (default 255), or `stamps`
+(wave-cycles per phase of the 16-query kernel from its instrumented build), or `debug` (the one-hot exact test of
+tests/test_ops_gpu.py with the list of (batch, head, query) rows that differ)."""
 import os
 import sys
 
@@ -15,7 +18,6 @@ v = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 debug.set("attn_v", v % 10)
 debug.set("attn_xcd", (v // 10) % 10)
 debug.set("attn_waves", v // 100)
-_=(0)                # 10, 12: the same kernels with the images dealt to the XCDs
 if len(sys.argv) > 2 and sys.argv[2] == "debug":
     t, batch, width = 257, 2, 256
     g = torch.Generator().manual_seed(3)
@@ -44,7 +46,28 @@ if len(sys.argv) > 2 and sys.argv[2] == "debug":
         match = [(j, float((vv[j] - gq).abs().max())) for j in range(t) if float((vv[j] - gq).abs().max()) < 0.51]
         print("  row", (b, h, q), "target", tk, "closest V rows:", match[:4], "got[:6]", gq[:6].tolist(), "want[:6]", want.view(batch, t, heads, 64)[b, q, h][:6].tolist())
     sys.exit(0)
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 255
+B = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "stamps" else 255
+if len(sys.argv) > 2 and sys.argv[2] == "stamps":
+    # the 16-query kernel with s_memtime stamps between its phases (attn_waves = 2 selects the instrumented build): wave-cycles per phase
+    import ctypes as C
+    from knowledge_enhanced_multimodal_retrieval_amd import _lib
+    g = torch.Generator(device=dev).manual_seed(0)
+    qkv = (torch.randn(B * 257, 3072, generator=g, device=dev) * 0.5).to(torch.bfloat16)
+    out = torch.zeros(B * 257 * 1024 + B * 16 * 4 * 8 * 4, dtype=torch.bfloat16, device=dev)
+    debug.set("attn_v", 0); debug.set("attn_xcd", 1); debug.set("attn_waves", 2)
+    L = _lib.lib()
+    n = 20
+    for _ in range(n):
+        _lib.check(L.kemr_op_attention(C.c_void_p(qkv.data_ptr()), C.c_void_p(out.data_ptr()), B, 257, 1024, 0, C.c_void_p(engine._stream_ptr(dev))), "op_attention")
+    torch.cuda.synchronize()
+    st = out[B * 257 * 1024:].view(torch.int64).view(-1, 8).sum(0).cpu().tolist()
+    waves = st[6]
+    names = ["staging", "S^T + K reads", "mask + max", "exp + sum", "PV + V reads", "normalise + store"]
+    tot = sum(st[:6])
+    print("waves", waves, "memtime ticks per wave", tot / waves)
+    for nme, v in zip(names, st[:6]):
+        print("  %-20s %8.0f ticks per wave  %5.1f %%" % (nme, v / waves, 100.0 * v / tot))
+    sys.exit(0)
 g = torch.Generator(device=dev).manual_seed(0)
 qkv = (torch.randn(B * 257, 3072, generator=g, device=dev) * 0.5).to(torch.bfloat16)
 for _ in range(300):
