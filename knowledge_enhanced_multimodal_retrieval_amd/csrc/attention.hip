@@ -679,8 +679,8 @@ __global__ __launch_bounds__(512, 4) void attention_w8_kernel(const bf16_t* __re
 // together, least of all: hence 168).  s_memtime stamps between the phases of the 16-query kernel (tools/prof_attention.py 10 stamps;
 // the instrumented build runs at the speed of the plain one) split a wave's life into 28 % staging (idle), 24 % S^T + K reads
 // (1 760 ticks per tile for 580 cycles of MFMA), 7 % mask + max, 14.5 % exponentials (1 050 per tile = 67 x 16: issue-bound), 19 %
-// PV + V reads (1 370 per tile for 580 of MFMA), 7 % normalise + store; 30.8 k ticks per wave in 18.7 us say the clock sits near
-// 1.65 GHz in this kernel.  At that clock the tiles of a launch cost 120 us of VALU + MFMA issue per SIMD (no overlap) and 92 us of
+// PV + V reads (1 370 per tile for 580 of MFMA), 7 % normalise + store; 30.8 k ticks per wave against the 18.7 us of a workgroup slot read either as
+// a clock near 1.65 GHz or, at the GEMM's ~2.0 GHz, as ~3 us of dispatch and drain per slot.  At 1.65 GHz the tiles of a launch cost 120 us of VALU + MFMA issue per SIMD (no overlap) and 92 us of
 // LDS reads per CU (71.7 KB per tile at 128 B / clk; eight waves share one LDS): the tile phases run within ~10 % of both, i.e. the
 // kernel is near the limit of THIS shape of the work, and a faster one has to change the shape: K / V fragments shared by two
 // query tiles (half the LDS bytes) AND the two pipes overlapped inside one instruction stream (max(1 800, 1 120) instead of their
