@@ -107,9 +107,9 @@ def gemm256u_census(arch, calls):
     QKV, out-proj, fc1, fc2 with A + W read once and C written once, all bf16 (the per-launch minimum the
     PMC traffic is compared with); with the residual add in the epilogue the out-proj and fc2 launches read their C tile too."""
     launches, nbytes = 0, 0.0
-    for kind, n, resadd in calls:
+    for kind, n, resadd, rows in calls:
         tokens, w, layers = (arch.v_tokens, arch.v_width, arch.v_layers) if kind == "image" else (arch.ctx, arch.t_width, arch.t_layers)
-        m = n * tokens
+        m = rows                                         # token rows of the call (texts: only the positions up to the end-of-text token)
         if m <= 512:
             continue                                     # the skinny kernel takes these
         for nn, kk in ((3 * w, w), (w, w), (4 * w, w), (w, 4 * w)):
@@ -121,8 +121,13 @@ def gemm256u_census(arch, calls):
 
 
 def gemm_flops_per_step_text(arch, batch):
-    """The text towers' share of gemm_flops_per_step (2 * batch texts)."""
+    """The text towers' share of gemm_flops_per_step (2 * batch texts, every one of the ctx positions)."""
     return 2.0 * (2 * batch * arch.ctx) * arch.t_layers * (arch.t_width * 3 * arch.t_width + arch.t_width * arch.t_width + 2 * arch.t_width * 4 * arch.t_width)
+
+
+def gemm_flops_per_text_row(arch):
+    """GEMM FLOPs one token row of the text tower costs (QKV, out-proj, fc1, fc2 of every layer)."""
+    return 2.0 * arch.t_layers * (arch.t_width * 3 * arch.t_width + arch.t_width * arch.t_width + 2 * arch.t_width * 4 * arch.t_width)
 
 
 def main():
@@ -137,11 +142,12 @@ def main():
     ap.add_argument("--image-slice", type=int, default=0, help="experiment: images per encoder launch (default: the engine's 255)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="A/B only: force a GEMM tile variant (0 = the library's choice)")
     ap.add_argument("--text-group", type=int, default=0, help="texts per encoder call (0 = engine.tile_friendly_batch: 851 for ViT-L/14; 255 = one call per text column and step, round 1 / early round 2)")
+    ap.add_argument("--full-context", action="store_true", help="compute all 77 positions of every text (the reference's arithmetic; default: only the positions up to the end-of-text token, which are the ones that can reach the embedding)")
     ap.add_argument("--resadd", type=int, default=-1, help="A/B: 1 / 0 = residual add inside the out-proj / fc2 epilogues on / off (default: the library's setting)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sim", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the host-pipeline sub-result (N = 1: uint8 sources through encode_dataset)")
-    ap.add_argument("--pipeline-items", type=int, default=8160, help="gallery items of the host-pipeline sub-result")
+    ap.add_argument("--pipeline-items", type=int, default=24480, help="gallery items of the host-pipeline sub-result")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp8 / bf16-res16 sub-results (two more engines, ~20 steps each)")
     args = ap.parse_args()
 
@@ -181,46 +187,79 @@ def main():
 
     g = torch.Generator().manual_seed(1234 + rank)
     pixels = torch.randn(B, 3, arch.image_size, arch.image_size, generator=g).to(dev)
-    q_ids = synthetic_ids(arch, B, 1235 + rank).to(dev)
-    t_ids = synthetic_ids(arch, B, 4321 + rank).to(dev)
+    q_host, t_host = synthetic_ids(arch, B, 1235 + rank), synthetic_ids(arch, B, 4321 + rank)     # what a tokenizer hands over: host ids
+    q_ids, t_ids = q_host.to(dev), t_host.to(dev)
+    q_lens, t_lens = engine.text_lengths(q_host), engine.text_lengths(t_host)                    # positions up to the end-of-text token
+    pack = eng.pack_text and not args.full_context
+    eng.pack_text = pack
 
     # Encoder calls sized for the persistent GEMM's rounds (engine.tile_friendly_batch): B = 255 images are 256 row tiles; the 2 B
     # texts a step brings are pooled and go text_group = 851 to a call (256 row tiles: whole rounds in every text GEMM; 255 texts
     # leave 10 % of the out-proj round empty; same box: 16 340 items/s at 255, 16 590 at 565, 16 710 at 848), the pool's rest is encoded when the timed region ends.  Every step
     # still encodes exactly B images + 2 B texts on average, and the region as a whole exactly steps x (B + 2 B) items.
-    text_group = args.text_group or (engine.tile_friendly_batch(arch.ctx, arch.t_width, B, engine.MAX_TEXT_BATCH) if B == 255 else 2 * B)
-    text_pool = torch.cat([q_ids, t_ids] * (-(-text_group // (2 * B))))[:text_group].contiguous()
+    # Packed texts (the default: only the positions up to a text's end-of-text token are computed, engine.encode_text): the pool is
+    # sized by TOKEN ROWS instead -- as many of the step's texts as fill engine.TEXT_ROW_BUDGET = 65 536 rows (256 row tiles).
+    pair_lens = torch.cat([q_lens, t_lens])
 
-    all_calls = []                 # every encoder call of this process, in order: (kind, items)
+    def make_pool(packed):
+        import types
+        if args.text_group:
+            group = args.text_group
+        elif packed:
+            reps_ = -(-engine.TEXT_ROW_BUDGET // int(pair_lens.sum())) + 1
+            group = max(2 * B, int((torch.cumsum(pair_lens.repeat(reps_).to(torch.int64), 0) <= engine.TEXT_ROW_BUDGET).sum()))
+        else:
+            group = engine.tile_friendly_batch(arch.ctx, arch.t_width, B, engine.MAX_TEXT_BATCH) if B == 255 else 2 * B
+        reps_ = -(-group // (2 * B))
+        lens_ = pair_lens.repeat(reps_)[:group].contiguous()                   # host tensor: the launches are sized without asking the device
+        csum = [0] + torch.cumsum(lens_.to(torch.int64), 0).tolist()           # rows of the first k texts of the pool
+        return types.SimpleNamespace(packed=packed, group=group, ids=torch.cat([q_ids, t_ids] * reps_)[:group].contiguous(), lens=lens_,
+                                     rows=(lambda k: csum[k]) if packed else (lambda k: k * arch.ctx))
+
+    main_pool = make_pool(pack)
+    text_group = main_pool.group
+
+    all_calls = []                 # every encoder call of this process, in order: (kind, items, resadd bytes, token rows)
 
     class Stepper:
-        def __init__(self, e, resadd):
+        def __init__(self, e, resadd, pool=None):
+            self.pool = pool or main_pool
             self.resadd = (2 if e.precision.endswith("res16") else 4) if resadd else 0      # bytes per in-place C element, census
             self.e, self.pending, self.images, self.texts, self.calls = e, 0, 0, 0, all_calls      # pooled texts; items encoded so far; the process-wide call list
+            self.text_rows = 0                         # token rows the text calls computed
 
         def step(self):
             a = self.e.encode_image(pixels, normalize=True)
-            self.calls.append(("image", B, self.resadd))
+            self.calls.append(("image", B, self.resadd, B * arch.v_tokens))
             self.images += B
             self.pending += 2 * B
-            while self.pending >= text_group:
-                self.e.encode_text(text_pool, normalize=True)
-                self.calls.append(("text", text_group, self.resadd))
-                self.pending -= text_group
-                self.texts += text_group
+            p = self.pool
+            self.e.pack_text = p.packed
+            while self.pending >= p.group:
+                self.e.encode_text(p.ids, normalize=True, lens=p.lens)
+                self.calls.append(("text", p.group, self.resadd, p.rows(p.group)))
+                self.pending -= p.group
+                self.texts += p.group
+                self.text_rows += p.rows(p.group)
             return a
 
         def drain(self):
             if self.pending:
-                self.e.encode_text(text_pool[:self.pending], normalize=True)
-                self.calls.append(("text", self.pending, self.resadd))
+                p = self.pool
+                self.e.pack_text = p.packed
+                self.e.encode_text(p.ids[:self.pending], normalize=True, lens=p.lens[:self.pending])
+                self.calls.append(("text", self.pending, self.resadd, p.rows(self.pending)))
                 self.texts += self.pending
+                self.text_rows += p.rows(self.pending)
                 self.pending = 0
 
         def check_outputs(self):            # the step's own items, for the oracle / cross-precision comparisons (untimed)
-            self.calls += [("image", B, self.resadd), ("text", B, self.resadd), ("text", B, self.resadd)]
-            return (self.e.encode_image(pixels, normalize=True), self.e.encode_text(q_ids, normalize=True),
-                    self.e.encode_text(t_ids, normalize=True))
+            pk = self.pool.packed
+            self.e.pack_text = pk
+            self.calls += [("image", B, self.resadd, B * arch.v_tokens), ("text", B, self.resadd, int(q_lens.sum()) if pk else B * arch.ctx),
+                           ("text", B, self.resadd, int(t_lens.sum()) if pk else B * arch.ctx)]
+            return (self.e.encode_image(pixels, normalize=True), self.e.encode_text(q_ids, normalize=True, lens=q_lens),
+                    self.e.encode_text(t_ids, normalize=True, lens=t_lens))
 
     main_steps = Stepper(eng, resadd_on)
     step, drain = main_steps.step, main_steps.drain
@@ -257,7 +296,8 @@ def main():
     shard_bounds = [[r * per_shard, min(GALLERY, (r + 1) * per_shard)] for r in range(world)]
     items = 3 * B * world * args.steps                       # images + query texts + target texts
     value = items / elapsed
-    flops_item_step = B * (arch.image_flops() + 2 * arch.text_flops())
+    row_frac = float(pair_lens.sum()) / (2 * B * arch.ctx) if pack else 1.0      # share of the text token rows that is computed
+    flops_item_step = B * (arch.image_flops() + 2 * arch.text_flops() * row_frac)  # executed, not the full-context count
     result = {
         "metric": "gallery images+texts encoded/sec (ViT-L/14) and 43k x Q sim+top-10 ms",
         "value": value, "unit": "items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -292,17 +332,24 @@ def main():
             split = kds.SyntheticHFSplit(n_pipe, 11)
             evaluators.encode_dataset(pm, kds.CLIPEvalDatasetHF(kds.SyntheticHFSplit(510, 12), ppre), 64, 1, 0)      # warm: kernels, workspaces
             barrier()
-            t1 = time.perf_counter()                                       # the host side alone (loader processes, pin thread): its ceiling
-            n_l = sum(len(b[3]) for b in evaluators.eval_loader(kds.CLIPEvalDatasetHF(kds.SyntheticHFSplit(n_pipe // 2, 13), ppre), 64, 1, workers,
-                                                                evaluators.default_tokenize, True))
-            loader_only = 3 * n_l / (time.perf_counter() - t1)
+            t1 = time.perf_counter()                                       # the host side alone (loader processes, pin thread): its ceiling,
+            n_l, t_first, n_first = 0, None, 0                             # and how long the worker processes take to deliver their first batch
+            for b_ in evaluators.eval_loader(kds.CLIPEvalDatasetHF(kds.SyntheticHFSplit(n_pipe // 4, 13), ppre), 64, 1, workers,
+                                             evaluators.default_tokenize, True):
+                n_l += len(b_[3])
+                if t_first is None:
+                    t_first, n_first = time.perf_counter() - t1, n_l
+            t_all = time.perf_counter() - t1
+            loader_only = 3 * n_l / t_all
+            loader_steady = 3 * (n_l - n_first) / max(t_all - t_first, 1e-9)
             t1 = time.perf_counter()
             pi, pq, pt, pids = evaluators.encode_dataset(pm, kds.CLIPEvalDatasetHF(split, ppre), 64, 1, workers)
             barrier()
             dtp = time.perf_counter() - t1
             assert pi.shape[0] == n_pipe and len(pids) == n_pipe and bool(torch.isfinite(pi).all())
             result["pipeline"] = {"items_per_s": 3 * n_pipe / dtp, "images_per_s": n_pipe / dtp, "seconds": dtp, "items": n_pipe,
-                                  "loader_workers": workers, "loader_batch": 64, "host_cores": os.cpu_count(), "loader_only_items_per_s": loader_only, "loader_context": os.environ.get("KEMR_LOADER_CONTEXT", "forkserver"),
+                                  "loader_workers": workers, "loader_batch": 64, "host_cores": os.cpu_count(), "loader_only_items_per_s": loader_only, "loader_first_batch_s": t_first,
+                                  "loader_only_items_per_s_after_first_batch": loader_steady, "loader_context": os.environ.get("KEMR_LOADER_CONTEXT", "forkserver"),
                                   "image_transform": "gpu" if ppre.defer_to_gpu else "host",
                                   "source": "uint8 PIL images of 8 camera-like sizes (224x224 .. 600x800) -> CLIPEvalDatasetHF(split, preprocess) -> "
                                             "evaluators.encode_dataset; worker start-up and PCIe included"}
@@ -316,7 +363,7 @@ def main():
 
     def profile_region(st):
         """10 steps of `st` under the library's per-class hipEvent timing -> (ms per class and step, GEMM launches per step, GEMM flops per step)."""
-        i0, t0_ = st.images, st.texts
+        i0, t0_, r0_ = st.images, st.texts, st.text_rows
         _lib.check(L.kemr_profile_begin(4096 * prof_steps))
         for _ in range(prof_steps):
             st.step()
@@ -325,7 +372,7 @@ def main():
         _lib.check(L.kemr_profile_end(ms_, cnt_, 5))
         n_img, n_txt = st.images - i0, st.texts - t0_
         st.drain()
-        fl = ((f_step - f_txt) * n_img / B + f_txt * n_txt / (2 * B)) / prof_steps      # of what the region actually launched
+        fl = ((f_step - f_txt) * n_img / B + gemm_flops_per_text_row(arch) * (st.text_rows - r0_)) / prof_steps      # of what the region actually launched
         return [m_ / prof_steps for m_ in ms_], cnt_[0] / prof_steps, fl
 
     ms, gemm_n, gemm_flops = profile_region(main_steps)
@@ -421,6 +468,34 @@ def main():
             result["roofline_sim"]["traffic"] = sj.get("bytes_per_launch")
             result["roofline_sim"]["traffic_source"] = {k: sj.get(k) for k in ("kernel", "profile", "round", "commit", "method")}
 
+    # ------------------------------------------------------------------ sub-result: the same steps with every text position computed
+    # The headline computes a text only up to its end-of-text token (the rows behind it cannot reach the pooled embedding: causal
+    # mask, reference pooling x[arange, text.argmax(-1)]); this leg runs the reference's full-context arithmetic -- 77 positions per
+    # text, 851 texts to a call -- on the same engine, and the embeddings of the two are compared.
+    result["text_packing"] = {"enabled": bool(pack), "text_rows_computed_fraction": row_frac,
+                              "mean_positions_per_text": float(pair_lens.float().mean()) if pack else float(arch.ctx), "context": arch.ctx,
+                              "texts_per_call": text_group,
+                              "lengths": "synthetic_ids: end-of-text token uniform in positions 8 .. 76 (unchanged since round 1)"}
+    if pack and not args.no_extras:
+        s4 = Stepper(eng, resadd_on, make_pool(False))
+        for _ in range(3):
+            s4.step()
+        s4.drain()
+        barrier()
+        n4 = 20
+        t1 = time.perf_counter()
+        for _ in range(n4):
+            s4.step()
+        s4.drain()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t1)
+        o4 = s4.check_outputs()
+        eng.pack_text = True
+        cos4 = [float(torch.nn.functional.cosine_similarity(a.double(), b.double()).min()) for a, b in zip(o4, out)]
+        result["text_packing"].update({"items_per_s_full_context": 3 * B * world * n4 / dt, "ms_per_step_full_context": 1e3 * dt / n4,
+                                       "speedup_vs_full_context": value / (3 * B * world * n4 / dt),
+                                       "min_cosine_vs_full_context_image_query_target": cos4})
+
     # ------------------------------------------------------------------ sub-results: the same step at other precisions
     recall_bar = {}
     rpath = os.path.join(ROOT, "profiles", "r03_recall_bar.json")
@@ -432,6 +507,7 @@ def main():
         for prec in ("bf16-res16", "fp8", "fp8-res16"):
             e2 = engine.ClipEngine(arch, dev, precision=prec)
             e2.load_state_dict(random_weights(arch, seed=0))
+            e2.pack_text = pack
 
             s2 = Stepper(e2, e2.residual_fusion_active())
             for _ in range(3):

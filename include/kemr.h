@@ -127,6 +127,21 @@ int kemr_encode_image(kemr_model* m, const float* pixels_dev, int batch, float* 
 int kemr_encode_text(kemr_model* m, const int32_t* ids_dev, int batch, float* out_dev, int normalize,
                      void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* The same text embeddings from the rows that can reach them.  The text transformer's mask is causal and the pooled row is the
+ * end-of-text token's (reference: `x[torch.arange(x.shape[0]), text.argmax(dim=-1)] @ self.text_projection` behind the masked
+ * transformer in the CLIP model `clip.load` returns; call sites as above), so positions behind that token cannot influence the
+ * output: text i is computed on its first lens[i] positions only, all texts packed one behind the other (`rows` = sum of lens
+ * token rows instead of B * ctx in every launch).  With lens[i] >= argmax_i + 1 the result is kemr_encode_text's up to the fp32
+ * summation order of the GEMM kernel a launch of that many rows is routed to -- what another batch size changes as well.
+ *   lens_dev : int32 [B] on the device, each in 1 .. ctx (clamped on the device)
+ *   rows     : HOST integer, the sum of lens (the tokenizer's side knows it; B <= rows <= B * ctx is checked, and the device
+ *              clamps the prefix sums into it, so no argument can make a kernel index outside the workspace)
+ *   workspace: >= kemr_text_packed_workspace_bytes(m, rows, B) bytes
+ * A length shorter than argmax_i + 1 pools text i's last computed row (memory-safe, not the reference's embedding). */
+size_t kemr_text_packed_workspace_bytes(const kemr_model* m, int rows, int batch);
+int kemr_encode_text_packed(kemr_model* m, const int32_t* ids_dev, const int32_t* lens_dev, int rows, int batch, float* out_dev,
+                            int normalize, void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Similarity + ranking.  Replaces `S = Q @ C.T`, the weighted T2I/T2T sum, and the two full
  * `np.argsort(-S)` passes of Recall@K / MRR (reference: src/clip/eval/metrics.py:13-76, 102,

@@ -55,6 +55,8 @@ SIGNATURES = {
     "kemr_workspace_bytes": (_sz, [_vp, _i, _i]),
     "kemr_encode_image": (_i, [_vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "kemr_encode_text": (_i, [_vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "kemr_text_packed_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "kemr_encode_text_packed": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "kemr_panel_kdim": (_i64, [_i, _i, _i]),
     "kemr_panel_build": (_i, [C.POINTER(_vp), C.POINTER(_f), C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp]),
     "kemr_sim_workspace_bytes": (_sz, [_i, _i, _i64, _i]),

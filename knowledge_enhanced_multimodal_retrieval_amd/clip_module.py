@@ -174,9 +174,14 @@ class CLIP(nn.Module):
     def encode_image(self, image: torch.Tensor, normalize: bool = False) -> torch.Tensor:
         return self.engine().encode_image(image.to(self.visual.proj.device), normalize=normalize)
 
+    accepts_text_lengths = True        # encode_text(..., lens=host int tensor): evaluators.encode_dataset passes the tokenizer-side lengths
+
     @torch.no_grad()
-    def encode_text(self, text: torch.Tensor, normalize: bool = False) -> torch.Tensor:
-        return self.engine().encode_text(text.to(self.visual.proj.device), normalize=normalize)
+    def encode_text(self, text: torch.Tensor, normalize: bool = False, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Host token ids (what ``tokenize`` returns) are handed over as they are: the engine reads the text lengths from them on the
+        host before the upload (engine.ClipEngine.encode_text); ids already on the GPU cost one small device-to-host copy unless the
+        caller passes ``lens`` (``engine.text_lengths(host_tokens)``)."""
+        return self.engine().encode_text(text, normalize=normalize, lens=lens)
 
     @torch.no_grad()
     def forward(self, image: torch.Tensor, text: torch.Tensor):

@@ -325,17 +325,23 @@ struct Workspace {
                     // an fp32 stream, else the (then still unused) h | delta pair, which is contiguous and as large
 };
 
+size_t ws_bytes_rows(int width, int64_t rows, int x_dtype) {
+    const int64_t Mp = round_up(rows, 256);
+    const int xb = x_dtype == KEMR_BF16 ? 2 : 4;
+    return (size_t)(round_up(Mp * width * xb, 256) + 3 * round_up(Mp * width * 2, 256) + round_up(Mp * width * 8, 256));
+}
+
 size_t ws_bytes(int width, int tokens, int batch, int x_dtype) {
     const int64_t Mp = round_up((int64_t)batch * tokens, 256);
     const int xb = x_dtype == KEMR_BF16 ? 2 : 4;
     return (size_t)(round_up(Mp * width * xb, 256) + 3 * round_up(Mp * width * 2, 256) + round_up(Mp * width * 8, 256));
 }
 
-int carve(Workspace& w, void* base, size_t bytes, int width, int tokens, int batch, int x_dtype) {
-    const size_t need = ws_bytes(width, tokens, batch, x_dtype);
+int carve(Workspace& w, void* base, size_t bytes, int width, int64_t rows, int x_dtype) {
+    const size_t need = ws_bytes_rows(width, rows, x_dtype);
     if (!base || bytes < need) KEMR_FAIL(KEMR_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", bytes, need);
     if ((uintptr_t)base % 256) KEMR_FAIL(KEMR_ERR_WORKSPACE, "workspace must be 256-byte aligned");
-    const int64_t Mp = round_up((int64_t)batch * tokens, 256);
+    const int64_t Mp = round_up(rows, 256);
     char* p = (char*)base;
     w.x = p; w.x_dtype = x_dtype; p += round_up(Mp * width * (x_dtype == KEMR_BF16 ? 2 : 4), 256);
     w.x32 = x_dtype == KEMR_BF16 ? (float*)p : (float*)w.x;
@@ -362,8 +368,10 @@ int carve(Workspace& w, void* base, size_t bytes, int width, int tokens, int bat
 //    the persistent kernel reaches its tile boundary at the same moment, so the 0.54 GB an epilogue round moves arrive as a burst
 //    at the HBM roofline with the matrix cores idle, and out-proj with 0.67 GB per launch is HBM-bound outright (122 us at best).
 // *pending = deltas left for the tail.
-int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, int fp8, int want_resadd, hipStream_t s, bool* pending) {
-    const int W = t.width, M = batch * t.tokens;
+// row_start / rows (text tower only): the token rows are packed, text i owning rows row_start[i] .. row_start[i + 1] - 1, `rows` in all.
+int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, int fp8, int want_resadd, hipStream_t s, bool* pending,
+               const int* row_start = nullptr, int rows = 0) {
+    const int W = t.width, M = row_start ? rows : batch * t.tokens;
     const bool fq = fp8 & 1, f1 = fp8 & 2;          // LayerNorm output = A operand of QKV / fc1: e4m3 where that GEMM runs in fp8
     bool resadd = want_resadd >= (w.x_dtype == KEMR_BF16 ? 1 : 2) && M > 512 && W % 256 == 0;
     const int cs = w.x_dtype == KEMR_BF16 ? 2 : 4;
@@ -390,7 +398,8 @@ int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, int f
         } else {
             KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
         }
-        KEMR_TRY(launch_attention(w.big, w.h, batch, t.tokens, W, causal, s));
+        if (row_start) KEMR_TRY(launch_attention_packed(w.big, w.h, row_start, batch, t.tokens, W, s));
+        else KEMR_TRY(launch_attention(w.big, w.h, batch, t.tokens, W, causal, s));
         g.A = w.h; g.lda = W; g.W = L.wo; g.ldw = W; g.bias = L.bo; g.C = resadd ? w.x : (void*)w.delta; g.ldc = W; g.N = W; g.K = W;
         KEMR_TRY(launch_gemm(g, resadd ? epi_res : EPI_BIAS_BF16, s));
         KEMR_TRY(launch_layernorm(w.x, w.x_dtype, resadd ? nullptr : w.delta, nullptr, 0, L.ln2_g, L.ln2_b, w.h, M, W, f1 ? KEMR_FP8 : KEMR_BF16, s));
@@ -417,6 +426,11 @@ extern "C" size_t kemr_workspace_bytes(const kemr_model* m, int tower, int batch
     return 0;
 }
 
+extern "C" size_t kemr_text_packed_workspace_bytes(const kemr_model* m, int rows, int batch) {
+    if (!m || batch <= 0 || rows < batch) return 0;
+    return ws_bytes_rows(m->cfg.t_width, rows, m->res_dtype) + (size_t)round_up(((int64_t)batch + 1) * 4, 256);   // buffers + row_start
+}
+
 extern "C" int kemr_encode_image(kemr_model* m, const float* pixels_dev, int batch, float* out_dev, int normalize,
                                  void* workspace_dev, size_t workspace_bytes, void* stream) {
     if (!m || !pixels_dev || !out_dev) KEMR_FAIL(KEMR_ERR_INVALID, "encode_image: null argument");
@@ -426,7 +440,7 @@ extern "C" int kemr_encode_image(kemr_model* m, const float* pixels_dev, int bat
     hipStream_t s = (hipStream_t)stream;
     const int W = m->cfg.v_width, T = m->patches + 1;
     Workspace w;
-    KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, T, batch, m->res_dtype));
+    KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, (int64_t)batch * T, m->res_dtype));
     KEMR_TRY(launch_im2col(pixels_dev, w.big, batch, m->cfg.image_size, m->cfg.patch, m->kpad, s));
     GemmParams g{};
     g.A = w.big; g.lda = m->kpad; g.W = m->conv_w; g.ldw = m->kpad; g.bias = nullptr; g.C = w.x32; g.ldc = W;
@@ -449,11 +463,43 @@ extern "C" int kemr_encode_text(kemr_model* m, const int32_t* ids_dev, int batch
     hipStream_t s = (hipStream_t)stream;
     const int W = m->cfg.t_width, T = m->cfg.ctx;
     Workspace w;
-    KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, T, batch, m->res_dtype));
+    KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, (int64_t)batch * T, m->res_dtype));
     KEMR_TRY(launch_text_embed(ids_dev, m->tok, m->tpos, w.x, w.x_dtype, batch, T, W, m->cfg.vocab, s));
     bool tb = false;
     KEMR_TRY(run_blocks(m->txt, w, batch, 1, m->fp8, m->resadd, s, &tb));
     KEMR_TRY(launch_tail(w.x, w.x_dtype, tb ? w.delta : nullptr, tb ? w.delta2 : nullptr, ids_dev, batch, T, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s));
+    return KEMR_OK;
+}
+
+// The text tower on the rows that can reach the output only.  The attention mask is causal and the pooled row is the end-of-text
+// token's (reference: model.encode_text -> x[arange, text.argmax(-1)]; open_clip / CLIP text transformer with attn_mask), so the
+// positions behind it never influence the embedding: text i is computed on its first lens_dev[i] positions, packed one text
+// behind the other (`rows` = sum(lens) rows instead of batch * ctx through every GEMM, LayerNorm and attention launch).  With
+// lens[i] >= argmax_i + 1 the embeddings are kemr_encode_text's -- the same arithmetic per row; the GEMM a launch of another M is
+// routed to may sum in another order, as for another batch size (tests/test_encoder_gpu.py: 1 - cos of a few 1e-5 both ways); a
+// shorter length pools the last computed row instead (memory-safe, wrong).  `rows` is a HOST integer: the tokenizer's side knows the lengths without
+// asking the device (the python wrapper derives lens and rows from the same host tokens); lengths and prefix sums are clamped on the
+// device (row_starts_kernel) so that no argument can index outside the workspace.
+extern "C" int kemr_encode_text_packed(kemr_model* m, const int32_t* ids_dev, const int32_t* lens_dev, int rows, int batch, float* out_dev,
+                                       int normalize, void* workspace_dev, size_t workspace_bytes, void* stream) {
+    if (!m || !ids_dev || !out_dev || !lens_dev) KEMR_FAIL(KEMR_ERR_INVALID, "encode_text_packed: null argument");
+    if (!m->finalized) KEMR_FAIL(KEMR_ERR_STATE, "encode_text_packed: model not finalized");
+    if (batch <= 0) return batch == 0 ? KEMR_OK : (set_error("encode_text_packed: negative batch"), KEMR_ERR_INVALID);
+    if ((int64_t)batch * m->cfg.ctx > (1 << 24)) KEMR_FAIL(KEMR_ERR_INVALID, "encode_text_packed: batch %d too large", batch);
+    if (m->cfg.ctx > 128) KEMR_FAIL(KEMR_ERR_INVALID, "encode_text_packed: context length %d > 128", m->cfg.ctx);
+    hipStream_t s = (hipStream_t)stream;
+    const int W = m->cfg.t_width, T = m->cfg.ctx;
+    if (rows < batch || (int64_t)rows > (int64_t)batch * T) KEMR_FAIL(KEMR_ERR_INVALID, "encode_text_packed: %d rows for %d texts of 1 .. %d positions", rows, batch, T);
+    const size_t base_bytes = ws_bytes_rows(W, rows, m->res_dtype), need = base_bytes + (size_t)round_up(((int64_t)batch + 1) * 4, 256);
+    if (workspace_bytes < need) KEMR_FAIL(KEMR_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    Workspace w;
+    KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, rows, m->res_dtype));
+    int* row_start = (int*)((char*)workspace_dev + base_bytes);
+    KEMR_TRY(launch_row_starts(lens_dev, batch, T, rows, row_start, s));
+    KEMR_TRY(launch_text_embed(ids_dev, m->tok, m->tpos, w.x, w.x_dtype, batch, T, W, m->cfg.vocab, s, row_start, rows));
+    bool tb = false;
+    KEMR_TRY(run_blocks(m->txt, w, batch, 1, m->fp8, m->resadd, s, &tb, row_start, rows));
+    KEMR_TRY(launch_tail(w.x, w.x_dtype, tb ? w.delta : nullptr, tb ? w.delta2 : nullptr, ids_dev, batch, T, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s, row_start));
     return KEMR_OK;
 }
 

@@ -45,8 +45,7 @@ __device__ __forceinline__ bool attn_item(int xbatch, int& h, int& b) {
 
 template <int NT32, bool CAUSAL, int TC, int NW = 4, bool STAMP = false>   // keys padded to NT32 * 32; NW waves per workgroup
 __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                           int T_rt, int width, int xbatch) {
-    const int T = TC > 0 ? TC : T_rt;
+                                                           int T_rt, int width, int xbatch, const int* __restrict__ row_start) {
     constexpr int TP = NT32 * 32;
     constexpr int NT16 = NT32 * 2;
     constexpr int NTH = NW * 64;
@@ -58,10 +57,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
 
     int h, b;
     if (!attn_item(xbatch, h, b)) return;
+    // row_start (run-time T only): items of different lengths packed one behind the other -- item b owns the rows row_start[b] ..
+    // row_start[b + 1] - 1 of qkv and of out (the text tower computes a caption only up to its end-of-text token)
+    int T_ = TC > 0 ? TC : T_rt;
+    size_t row0 = (size_t)b * T_;
+    if (TC == 0 && row_start) {
+        const int r0 = row_start[b];
+        T_ = row_start[b + 1] - r0;
+        row0 = r0;
+    }
+    const int T = T_;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ld = 3 * width;
-    const bf16_t* base = qkv + (size_t)b * T * ld + h * 64;
+    const bf16_t* base = qkv + row0 * ld + h * 64;
     const int lrow = lane & 15, lq = lane >> 4;
     const int nqt = (T + 15) >> 4;
 
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
         // o[dt][r] = O[query lrow][d = dt*16 + lq*4 + r]
         if (q < T) {
             const float inv = 1.0f / sum;
-            bf16_t* dst = out + ((size_t)b * T + q) * width + h * 64 + lq * 4;
+            bf16_t* dst = out + (row0 + q) * width + h * 64 + lq * 4;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 uint2 pk;
@@ -798,16 +807,16 @@ static int attention_num_cu(int* out) {                 // (as the persistent GE
 }
 
 template <int NT32>
-static int launch_nt(const bf16_t* qkv, bf16_t* out, int batch, int t, int width, int causal, hipStream_t stream) {
+static int launch_nt(const bf16_t* qkv, bf16_t* out, int batch, int t, int width, int causal, hipStream_t stream, const int* row_start = nullptr) {
     constexpr int smem = NT32 * 32 * 128 * 2;
     const dim3 grid(width / 64, batch);
     ProfScope prof(PROF_ATTENTION, stream);
-    void (*kern)(const bf16_t*, bf16_t*, int, int, int);
+    void (*kern)(const bf16_t*, bf16_t*, int, int, int, const int*);
     const int xbatch = g_attn_xcd ? batch : 0;
     const dim3 xgrid(width / 64, xbatch ? (batch + 7) / 8 * 8 : batch);
     int threads = 256;
     if (causal) {
-        if (NT32 == 3 && t == 77) { kern = attention_kernel<NT32, true, NT32 == 3 ? 77 : 0, NT32 == 3 ? 5 : 4>; threads = 320; }
+        if (NT32 == 3 && t == 77 && !row_start) { kern = attention_kernel<NT32, true, NT32 == 3 ? 77 : 0, NT32 == 3 ? 5 : 4>; threads = 320; }
         else kern = attention_kernel<NT32, true, 0>;
     } else if (NT32 == 9 && t == 257 && g_attn_v >= 2) {
         if (g_attn_v == 3) {
@@ -844,7 +853,7 @@ static int launch_nt(const bf16_t* qkv, bf16_t* out, int batch, int t, int width
         kern = attention_kernel<NT32, false, 0>;
     }
     KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    hipLaunchKernelGGL(kern, xgrid, dim3(threads), smem, stream, qkv, out, t, width, xbatch);
+    hipLaunchKernelGGL(kern, xgrid, dim3(threads), smem, stream, qkv, out, t, width, xbatch, row_start);
     KEMR_CHECK_LAUNCH("attention_kernel");
     return KEMR_OK;
 }
@@ -866,6 +875,22 @@ int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int t, int width
         case 9: return launch_nt<9>(qkv, out, batch, t, width, causal, stream);
     }
     KEMR_FAIL(KEMR_ERR_INVALID, "attention: sequence length %d > 288 not supported", t);
+}
+
+// Causal attention over items of different lengths packed one behind the other: item b = rows row_start[b] .. row_start[b + 1] - 1
+// (device array of batch + 1 ints), every length in 1 .. max_t.
+int launch_attention_packed(const bf16_t* qkv, bf16_t* out, const int* row_start, int batch, int max_t, int width, hipStream_t stream) {
+    if (batch <= 0) return KEMR_OK;
+    if (!row_start) KEMR_FAIL(KEMR_ERR_INVALID, "attention: packed rows need row_start");
+    if (width % 64 != 0 || max_t <= 0) KEMR_FAIL(KEMR_ERR_INVALID, "attention: bad shape t=%d width=%d", max_t, width);
+    if (batch > 65535) KEMR_FAIL(KEMR_ERR_INVALID, "attention: batch %d > 65535", batch);
+    switch ((max_t + 31) / 32) {
+        case 1: return launch_nt<1>(qkv, out, batch, max_t, width, 1, stream, row_start);
+        case 2: return launch_nt<2>(qkv, out, batch, max_t, width, 1, stream, row_start);
+        case 3: return launch_nt<3>(qkv, out, batch, max_t, width, 1, stream, row_start);
+        case 4: return launch_nt<4>(qkv, out, batch, max_t, width, 1, stream, row_start);
+    }
+    KEMR_FAIL(KEMR_ERR_INVALID, "attention: packed rows support lengths up to 128, got %d", max_t);
 }
 
 }  // namespace kemr

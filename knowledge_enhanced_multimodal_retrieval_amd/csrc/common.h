@@ -178,13 +178,19 @@ extern int g_gemm_variant;   // 0 auto, 1 = 128x128 (gemm.hip), 2 / 3 = 256x256 
 int launch_layernorm(void* x, int x_dtype, const bf16_t* delta, const bf16_t* delta2, int writeback, const float* gamma,
                      const float* beta, void* y, int rows, int width, int out_dtype, hipStream_t stream);
 int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int t, int width, int causal, hipStream_t stream);
+// causal, items of lengths 1 .. max_t packed one behind the other: item b = rows row_start[b] .. row_start[b + 1] - 1 (device ints)
+int launch_attention_packed(const bf16_t* qkv, bf16_t* out, const int* row_start, int batch, int max_t, int width, hipStream_t stream);
 int launch_im2col(const float* pixels, bf16_t* patches, int batch, int image_size, int patch, int kpad, hipStream_t stream);
 int launch_cls_rows(float* x, const float* class_emb, const float* pos, int batch, int tokens, int width, hipStream_t stream);
+// exclusive prefix sums of the (clamped) text lengths: the packed-row layout of the text tower
+int launch_row_starts(const int32_t* lens, int batch, int max_len, int rows, int* row_start, hipStream_t stream);
+// row_start (optional, device, batch + 1 ints): packed rows -- text i contributes only its first row_start[i + 1] - row_start[i]
+// positions, `rows` in total
 int launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos, void* x, int x_dtype, int batch, int ctx,
-                      int width, int vocab, hipStream_t stream);
+                      int width, int vocab, hipStream_t stream, const int* row_start = nullptr, int rows = 0);
 // pooled row -> LayerNorm -> @ proj [width, d] -> optional L2 normalise.  ids == nullptr: row = b * tokens (CLS)
 // delta, delta2 (optional): the last block's pending residual updates, added to the pooled row
 int launch_tail(const void* x, int x_dtype, const bf16_t* delta, const bf16_t* delta2, const int32_t* ids, int batch, int tokens, int width, const float* gamma,
-                const float* beta, const float* proj, int d, int normalize, float* out, hipStream_t stream);
+                const float* beta, const float* proj, int d, int normalize, float* out, hipStream_t stream, const int* row_start = nullptr);
 
 }  // namespace kemr

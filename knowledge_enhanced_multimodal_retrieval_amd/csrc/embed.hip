@@ -65,17 +65,67 @@ int launch_cls_rows(float* x, const float* class_emb, const float* pos, int batc
     return KEMR_OK;
 }
 
+// row_start[i] = lens[0] + .. + lens[i - 1] for the packed text rows (one workgroup; batch <= 65535).  Whatever the caller passed,
+// the result is safe to index with: every length is clamped into 1 .. max_len and the prefix sums into `rows` such that every text
+// keeps at least one row (row_start[i] <= rows - (batch - i)); with honest arguments (rows = the sum) the clamps change nothing.
+__global__ __launch_bounds__(1024) void row_starts_kernel(const int32_t* __restrict__ lens, int batch, int max_len, int rows,
+                                                          int* __restrict__ row_start) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, per = (batch + 1023) / 1024;
+    const int i0 = tid * per, i1 = i0 + per < batch ? i0 + per : batch;
+    int sum = 0;
+    for (int i = i0; i < i1; ++i) { const int l = lens[i]; sum += l < 1 ? 1 : (l > max_len ? max_len : l); }
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                // inclusive scan of the per-thread sums
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - sum;                          // exclusive
+    if (tid == 0) row_start[0] = 0;
+    for (int i = i0; i < i1; ++i) {
+        const int l = lens[i];
+        run += l < 1 ? 1 : (l > max_len ? max_len : l);
+        const int cap = rows - (batch - (i + 1));
+        row_start[i + 1] = run < cap ? run : cap;
+    }
+}
+
+int launch_row_starts(const int32_t* lens, int batch, int max_len, int rows, int* row_start, hipStream_t stream) {
+    if (batch <= 0) return KEMR_OK;
+    if (batch > 65535) KEMR_FAIL(KEMR_ERR_INVALID, "row_starts: batch %d > 65535", batch);
+    if (rows < batch || (int64_t)rows > (int64_t)batch * max_len) KEMR_FAIL(KEMR_ERR_INVALID, "row_starts: %d rows for %d texts of 1 .. %d positions", rows, batch, max_len);
+    ProfScope prof(PROF_OTHER, stream);
+    hipLaunchKernelGGL(row_starts_kernel, dim3(1), dim3(1024), 0, stream, lens, batch, max_len, rows, row_start);
+    KEMR_CHECK_LAUNCH("row_starts_kernel");
+    return KEMR_OK;
+}
+
 template <typename XT>
 __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids, const float* __restrict__ tok,
                                                          const float* __restrict__ pos, XT* __restrict__ x,
-                                                         int ctx, int width, int vocab, long long total4) {
+                                                         int ctx, int width, int vocab, long long total4,
+                                                         const int* __restrict__ row_start, int batch) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= total4) return;
     const int w4 = width >> 2;
     const long long row = gid / w4;
     const int c4 = (int)(gid - row * w4);
-    const int t = (int)(row % ctx);
-    int id = ids[row];
+    int t = (int)(row % ctx);
+    long long src = row;
+    if (row_start) {                  // packed rows: text i owns the rows row_start[i] .. row_start[i + 1] - 1 = its first positions
+        int lo = 0, hi = batch - 1;   // the last i with row_start[i] <= row
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (row_start[mid] <= row) lo = mid; else hi = mid - 1;
+        }
+        t = (int)(row - row_start[lo]);
+        t = t < ctx ? t : ctx - 1;    // (rows behind the last text, if the caller's row count exceeds the sum of the lengths)
+        src = (long long)lo * ctx + t;
+    }
+    int id = ids[src];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // out-of-range ids are clamped (torch would raise)
     const float4 a = ((const float4*)(tok + (size_t)id * width))[c4];
     const float4 p = ((const float4*)(pos + (size_t)t * width))[c4];
@@ -90,15 +140,15 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
 }
 
 int launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos, void* x, int x_dtype, int batch, int ctx,
-                      int width, int vocab, hipStream_t stream) {
-    const long long total4 = (long long)batch * ctx * (width / 4);
+                      int width, int vocab, hipStream_t stream, const int* row_start, int rows) {
+    const long long total4 = (row_start ? (long long)rows : (long long)batch * ctx) * (width / 4);
     if (total4 <= 0) return KEMR_OK;
     ProfScope prof(PROF_OTHER, stream);
     const dim3 grid((unsigned)((total4 + 255) / 256));
     if (x_dtype == KEMR_BF16)
-        hipLaunchKernelGGL(text_embed_kernel<bf16_t>, grid, dim3(256), 0, stream, ids, tok_emb, pos, (bf16_t*)x, ctx, width, vocab, total4);
+        hipLaunchKernelGGL(text_embed_kernel<bf16_t>, grid, dim3(256), 0, stream, ids, tok_emb, pos, (bf16_t*)x, ctx, width, vocab, total4, row_start, batch);
     else
-        hipLaunchKernelGGL(text_embed_kernel<float>, grid, dim3(256), 0, stream, ids, tok_emb, pos, (float*)x, ctx, width, vocab, total4);
+        hipLaunchKernelGGL(text_embed_kernel<float>, grid, dim3(256), 0, stream, ids, tok_emb, pos, (float*)x, ctx, width, vocab, total4, row_start, batch);
     KEMR_CHECK_LAUNCH("text_embed_kernel");
     return KEMR_OK;
 }
@@ -121,7 +171,7 @@ __global__ __launch_bounds__(256) void tail_proj_kernel(const XT* __restrict__ x
                                                         const bf16_t* __restrict__ delta2, const int32_t* __restrict__ ids,
                                                         int tokens, int width, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ proj,
-                                                        int d, float* __restrict__ out) {
+                                                        int d, float* __restrict__ out, const int* __restrict__ row_start) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* y = (float*)smem;          // [width] normalised row
     float* red = y + width;           // [4]
@@ -146,7 +196,13 @@ __global__ __launch_bounds__(256) void tail_proj_kernel(const XT* __restrict__ x
         if (tid == 0) *pool = best_t;
     }
     __syncthreads();
-    const size_t prow = (size_t)b * tokens + *pool;
+    // packed rows (text tower): the pooled position inside the rows this text owns (its length covers the end-of-text token when
+    // the caller kept the contract; clamped so that a short length reads its last row instead of a neighbour's)
+    size_t prow = (size_t)b * tokens + *pool;
+    if (row_start) {
+        const int r0 = row_start[b], len = row_start[b + 1] - r0;
+        prow = (size_t)r0 + (*pool < len ? *pool : len - 1);
+    }
     const XT* xr = x + prow * width;
     const bf16_t* dr = delta ? delta + prow * width : nullptr;
     const bf16_t* dr2 = delta2 ? delta2 + prow * width : nullptr;
@@ -199,7 +255,7 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x,
 }
 
 int launch_tail(const void* x, int x_dtype, const bf16_t* delta, const bf16_t* delta2, const int32_t* ids, int batch, int tokens, int width, const float* gamma,
-                const float* beta, const float* proj, int d, int normalize, float* out, hipStream_t stream) {
+                const float* beta, const float* proj, int d, int normalize, float* out, hipStream_t stream, const int* row_start) {
     if (batch <= 0) return KEMR_OK;
     if (d % 4 != 0 || d <= 0) KEMR_FAIL(KEMR_ERR_INVALID, "tail: embed_dim %d must be a positive multiple of 4", d);
     if (batch > 65535) KEMR_FAIL(KEMR_ERR_INVALID, "tail: batch %d > 65535", batch);
@@ -207,9 +263,9 @@ int launch_tail(const void* x, int x_dtype, const bf16_t* delta, const bf16_t* d
     ProfScope prof(PROF_OTHER, stream);
     const dim3 grid((d + 63) / 64, batch);
     if (x_dtype == KEMR_BF16)
-        hipLaunchKernelGGL(tail_proj_kernel<bf16_t>, grid, dim3(256), smem, stream, (const bf16_t*)x, delta, delta2, ids, tokens, width, gamma, beta, proj, d, out);
+        hipLaunchKernelGGL(tail_proj_kernel<bf16_t>, grid, dim3(256), smem, stream, (const bf16_t*)x, delta, delta2, ids, tokens, width, gamma, beta, proj, d, out, row_start);
     else
-        hipLaunchKernelGGL(tail_proj_kernel<float>, grid, dim3(256), smem, stream, (const float*)x, delta, delta2, ids, tokens, width, gamma, beta, proj, d, out);
+        hipLaunchKernelGGL(tail_proj_kernel<float>, grid, dim3(256), smem, stream, (const float*)x, delta, delta2, ids, tokens, width, gamma, beta, proj, d, out, row_start);
     KEMR_CHECK_LAUNCH("tail_proj_kernel");
     if (normalize) {
         hipLaunchKernelGGL(l2norm_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, stream, out, batch, d);

@@ -6,6 +6,7 @@ PyTorch is plumbing here (device memory, streams): every tensor that crosses int
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Mapping, Optional, Sequence, Tuple
 
 import torch
@@ -17,6 +18,13 @@ from .config import ClipArch
 # workspace (14 * width bytes per token) stays small; larger user batches are processed in slices.
 MAX_IMAGE_BATCH = 255
 MAX_TEXT_BATCH = 851
+TEXT_ROW_BUDGET = 65536        # token rows per packed text call: 256 row tiles of 256
+
+
+def text_lengths(ids: torch.Tensor) -> torch.Tensor:
+    """Positions of every text that can reach its embedding: up to and including the pooled one, ``ids.argmax(-1) + 1`` (the
+    end-of-text token has the largest id; reference pooling ``x[arange, text.argmax(dim=-1)]``).  int32 [B], on ids' device."""
+    return (ids.argmax(dim=-1) + 1).to(torch.int32)
 
 
 def tile_friendly_batch(tokens: int, width: int, lo: int, hi: int, num_cu: int = 256) -> int:
@@ -66,8 +74,9 @@ class ClipEngine:
         h = C.c_void_p()
         _lib.check(self._L.kemr_model_create(C.byref(cfg), C.byref(h)), "model_create")
         self._h = h
-        self._ws: Dict[int, torch.Tensor] = {}
+        self._ws: Dict[object, torch.Tensor] = {}
         self.ready = False
+        self.pack_text = os.environ.get("KEMR_TEXT_PACKED", "1") != "0"     # encode_text: only the positions up to the end-of-text token
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -145,13 +154,61 @@ class ClipEngine:
         pixels = pixels.to(dtype=torch.float32).contiguous()
         return self._encode(self._L.kemr_encode_image, _lib.TOWER_VISION, pixels, MAX_IMAGE_BATCH, normalize)
 
-    def encode_text(self, ids: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+    def encode_text(self, ids: torch.Tensor, normalize: bool = False, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``model.encode_text(tokens)`` (+ the optional L2 normalisation).  The rows behind a text's end-of-text token cannot reach
+        its embedding (causal mask, pooled at ``tokens.argmax(-1)``), so by default only the first ``lens[i] = argmax_i + 1``
+        positions of every text are computed, packed one text behind the other (kemr_encode_text_packed: the same embeddings --
+        up to the summation order of the GEMM kernel a launch of that many rows is routed to, as with another batch size -- from
+        sum(lens) instead of B * ctx token rows in every launch).  The lengths must be known on the HOST to size the launches:
+
+        * ``ids`` on the host (what a tokenizer returns): lengths are taken from it there, then it is uploaded -- no device sync;
+        * ``ids`` on the GPU with ``lens`` (host int tensor [B], ``text_lengths(host_tokens)``): no device sync;
+        * ``ids`` on the GPU alone: one small device-to-host copy (B ints) per call, unless ``KEMR_TEXT_PACK_SYNC=0``, which sends
+          such calls through the full-context kernel instead.
+
+        ``KEMR_TEXT_PACKED=0`` (or ``self.pack_text = False``) computes every position, as the reference does."""
         a = self.arch
-        _require_cuda(ids, "token ids")
         if ids.dim() != 2 or ids.shape[1] != a.ctx:
             raise RuntimeError(f"encode_text expects [B,{a.ctx}] token ids, got {tuple(ids.shape)}")
-        ids = ids.to(dtype=torch.int32).contiguous()
-        return self._encode(self._L.kemr_encode_text, _lib.TOWER_TEXT, ids, MAX_TEXT_BATCH, normalize)
+        if not self.ready:
+            raise RuntimeError("ClipEngine: load_state_dict() must be called before encoding")
+        pack = self.pack_text and a.ctx <= 128
+        if pack and lens is None and not ids.is_cuda:
+            lens = text_lengths(ids)
+        ids = ids.to(device=self.device, dtype=torch.int32, non_blocking=True).contiguous()
+        _require_cuda(ids, "token ids")
+        if pack and lens is None and os.environ.get("KEMR_TEXT_PACK_SYNC", "1") != "0":
+            lens = text_lengths(ids).cpu()                    # the one synchronising copy of this path
+        if not pack or lens is None:
+            return self._encode(self._L.kemr_encode_text, _lib.TOWER_TEXT, ids, MAX_TEXT_BATCH, normalize)
+        n = ids.shape[0]
+        lens = torch.as_tensor(lens, dtype=torch.int32, device="cpu").reshape(-1).clamp(1, a.ctx).contiguous()
+        if lens.numel() != n:
+            raise RuntimeError(f"encode_text: {lens.numel()} lengths for {n} texts")
+        out = torch.empty((n, a.embed_dim), dtype=torch.float32, device=self.device)
+        if n == 0:
+            return out
+        lens_dev = lens.to(self.device, non_blocking=True)
+        # calls of at most TEXT_ROW_BUDGET token rows (256 row tiles of the persistent GEMM: whole rounds, engine.tile_friendly_batch)
+        csum = torch.cumsum(lens.to(torch.int64), 0).tolist()
+        with torch.cuda.device(self.device):
+            stream = _stream_ptr(self.device)
+            s0, base = 0, 0
+            while s0 < n:
+                s1 = s0 + 1
+                while s1 < n and csum[s1] - base <= TEXT_ROW_BUDGET and s1 - s0 < 65535:
+                    s1 += 1
+                rows = csum[s1 - 1] - base
+                need = int(self._L.kemr_text_packed_workspace_bytes(self._h, rows, s1 - s0))
+                ws = self._ws.get("text_packed")
+                if ws is None or ws.numel() < need:
+                    ws = self._ws["text_packed"] = torch.empty(max(need, int(self._L.kemr_text_packed_workspace_bytes(
+                        self._h, min(TEXT_ROW_BUDGET, n * a.ctx), min(n, 65535)))), dtype=torch.uint8, device=self.device)
+                _lib.check(self._L.kemr_encode_text_packed(self._h, C.c_void_p(ids[s0:].data_ptr()), C.c_void_p(lens_dev[s0:].data_ptr()),
+                                                           rows, s1 - s0, C.c_void_p(out[s0:].data_ptr()), 1 if normalize else 0,
+                                                           C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(stream)), "encode_text_packed")
+                s0, base = s1, csum[s1 - 1]
+        return out
 
 
 # ====================================================================== similarity / ranking ops

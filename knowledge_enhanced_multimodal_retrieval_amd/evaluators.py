@@ -130,8 +130,12 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
     arch = getattr(model, "arch", None)
     n_img = ENCODE_ITEMS if arch is None else engine.tile_friendly_batch(arch.v_tokens, arch.v_width, ENCODE_ITEMS // 2, ENCODE_ITEMS)
     n_txt = ENCODE_ITEMS if arch is None else max(1, engine.tile_friendly_batch(arch.ctx, arch.t_width, ENCODE_ITEMS, engine.MAX_TEXT_BATCH) // 2)
-    pend_i, pend_q, pend_t = [], [], []
-    count = {"i": 0, "t": 0}
+    pend_i, pend_q, pend_t, pend_ql, pend_tl = [], [], [], [], []
+    count = {"i": 0, "t": 0, "rows": 0}
+    # Packed text calls (engine.ClipEngine.encode_text: a text is computed up to its end-of-text token only): the tokenizer-side
+    # lengths travel with the ids, and a call takes as many (query, target) pairs as fill engine.TEXT_ROW_BUDGET token rows.
+    by_rows = bool(getattr(model, "accepts_text_lengths", False)) and arch is not None and arch.ctx <= 128 and \
+        os.environ.get("KEMR_TEXT_PACKED", "1") != "0"
 
     def flush_images(final: bool):
         take = count["i"] if final else (count["i"] // n_img) * n_img              # whole encoder calls; the rest waits
@@ -143,6 +147,24 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
         count["i"] -= take
 
     def flush_texts(final: bool):
+        if by_rows:
+            if count["t"] <= 0:
+                return
+            cq, ct, lq, lt = torch.cat(pend_q), torch.cat(pend_t), torch.cat(pend_ql), torch.cat(pend_tl)
+            pair_rows = torch.cumsum((lq + lt).to(torch.int64), 0)
+            s0, base = 0, 0
+            while s0 < count["t"]:
+                s1 = s0 + max(1, int((pair_rows[s0:] - base <= engine.TEXT_ROW_BUDGET).sum()))
+                if s1 >= count["t"] and not final:
+                    break                                                          # not a whole call yet: wait for more
+                both = model.encode_text(torch.cat([cq[s0:s1], ct[s0:s1]]), normalize=True, lens=torch.cat([lq[s0:s1], lt[s0:s1]]))
+                qry.append(both[: s1 - s0])
+                tgt.append(both[s1 - s0:])
+                base, s0 = int(pair_rows[s1 - 1]), s1
+            pend_q[:], pend_t[:], pend_ql[:], pend_tl[:] = [cq[s0:]], [ct[s0:]], [lq[s0:]], [lt[s0:]]
+            count["t"] -= s0
+            count["rows"] = int(pair_rows[-1]) - base if s0 < pair_rows.numel() else 0
+            return
         take = count["t"] if final else (count["t"] // n_txt) * n_txt
         if take <= 0:
             return
@@ -162,6 +184,11 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
                 gpu_pre = ClipPreprocessGPU(int(getattr(getattr(model, "visual", None), "input_resolution", 224)), device)
             images = gpu_pre.batch(images)
         pend_i.append(images.to(device, non_blocking=True))
+        if by_rows:                            # lengths from the host copy, before the upload
+            lq_, lt_ = engine.text_lengths(q_ids.cpu()), engine.text_lengths(t_ids.cpu())
+            pend_ql.append(lq_)
+            pend_tl.append(lt_)
+            count["rows"] += int(lq_.sum()) + int(lt_.sum())
         pend_q.append(q_ids.to(device, non_blocking=True))
         pend_t.append(t_ids.to(device, non_blocking=True))
         count["i"] += int(images.shape[0])
@@ -169,7 +196,7 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
         uuids.extend(ids)
         if count["i"] >= n_img:
             flush_images(False)
-        if count["t"] >= n_txt:
+        if (count["rows"] > engine.TEXT_ROW_BUDGET) if by_rows else (count["t"] >= n_txt):
             flush_texts(False)
     flush_images(True)
     flush_texts(True)

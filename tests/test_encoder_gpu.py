@@ -72,8 +72,10 @@ def test_batch_slicing_and_determinism(device):
     assert torch.equal(full, again)
     assert torch.equal(full[-37:], part)
     ids = clip_ref.synthetic_ids(clip_ref.ARCHS["tiny"], engine.MAX_TEXT_BATCH + 5).to(device)
-    t_full = eng.encode_text(ids)
+    eng.pack_text = False                  # the full-context path slices by MAX_TEXT_BATCH texts (the packed one by token rows:
+    t_full = eng.encode_text(ids)          # test_text_rows_behind_the_eot_are_not_needed)
     assert torch.equal(t_full[-5:], eng.encode_text(ids[-5:]))
+    eng.pack_text = True
     assert eng.encode_image(px[:0]).shape == (0, arch.embed_dim)
 
 
@@ -275,3 +277,54 @@ def test_recall_at_10_default_against_oracle_and_fp8_within_0p2(device):
                    "inside_bar": bool(abs(res[(p, lvl)]["T2I_R@10"] - ref) <= RECALL_BAR + 1e-9)} for p in precs[1:]}
         print(f"level {lvl}: default R@10 {ref:.3f};", rec)
         assert rec["fp8"]["inside_bar"], (lvl, rec["fp8"])
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16-res16", "fp8"])
+@pytest.mark.parametrize("name,ntxt", [("tiny", 37), ("ViT-B/32", 300), ("ViT-L/14", 130)])
+def test_text_rows_behind_the_eot_are_not_needed(device, name, ntxt, precision):
+    """kemr_encode_text_packed (the default of ClipEngine.encode_text): every text computed on its first argmax + 1 positions only,
+    all texts packed one behind the other, against kemr_encode_text on all ctx positions (causal mask + pooling at the end-of-text
+    token: reference `x[arange, text.argmax(-1)]`), for lengths from 1 to ctx, host ids (no device sync), device ids + host
+    lengths, device ids alone, and several calls' worth of rows.  The two are the same arithmetic per row; what differs is the number
+    of rows M of every GEMM, and with it the kernel a launch is routed to (gemm.hip launch_gemm: persistent / skinny / ragged last
+    tile) and its fp32 summation order -- exactly what another batch size does to the full-context path (checked below), 1 - cos of
+    a few 1e-5 against the parity bar's 1e-3.  Calls that route alike are bit-identical."""
+    arch, sd, eng = _engine(name, device, precision=precision)
+    oa = clip_ref.ARCHS[name]
+    ids = clip_ref.synthetic_ids(oa, ntxt)
+    eot = int(ids.max())
+    ids[0] = 0; ids[0, 0] = eot                              # length 1: the pooled row is the first
+    ids[1] = 1; ids[1, arch.ctx - 1] = eot                   # length ctx
+    ids[2, :] = 0                                            # all zero: argmax 0
+    lens = engine.text_lengths(ids)
+    assert int(lens[0]) == 1 and int(lens[1]) == arch.ctx and int(lens[2]) == 1 and int(lens.min()) >= 1
+    close = lambda x, y: float((1 - _cos(x, y)).max())
+    eng.pack_text = False
+    full = eng.encode_text(ids.to(device), normalize=True)
+    other_batch = close(eng.encode_text(ids[:ntxt // 2].to(device), normalize=True), full[:ntxt // 2])
+    eng.pack_text = True
+    a = eng.encode_text(ids, normalize=True)                                  # host ids
+    b = eng.encode_text(ids.to(device), normalize=True, lens=lens)           # device ids + host lengths
+    c = eng.encode_text(ids.to(device), normalize=True)                      # device ids alone (one small D2H copy)
+    assert torch.equal(a, b) and torch.equal(a, c)
+    tol = 2e-4 if precision == "fp8" else 1e-4
+    print(f"{name} {precision}: packed vs full-context 1 - cos max {close(a, full):.2e}; full-context, half the batch: {other_batch:.2e}")
+    assert close(a, full) < tol and other_batch < tol
+    ref = clip_ref.l2_normalize(clip_ref.encode_text(sd, oa, ids[:24]))
+    assert close(a[:24].cpu(), ref) < (COS_TOL if precision != "fp8" else 5e-3)
+    old = engine.TEXT_ROW_BUDGET
+    try:                                                                     # many small calls: the chunking by rows
+        engine.TEXT_ROW_BUDGET = 5 * arch.ctx
+        d = eng.encode_text(ids, normalize=True)
+    finally:
+        engine.TEXT_ROW_BUDGET = old
+    assert close(d, full) < 2 * tol
+    # a length that stops short of the end-of-text token pools the last computed row: not the reference's embedding, but finite and
+    # in bounds, and the other texts of the call are untouched; longer than needed changes nothing beyond the route
+    short = lens.clone(); short[3] = max(1, int(lens[3]) - 2)
+    e = eng.encode_text(ids.to(device), normalize=True, lens=short)
+    assert torch.isfinite(e).all() and close(e[4:], a[4:]) < tol
+    longer = (lens + 3).clamp(max=arch.ctx)
+    assert close(eng.encode_text(ids.to(device), normalize=True, lens=longer), a) < tol
+    with pytest.raises(RuntimeError, match="lengths"):
+        eng.encode_text(ids.to(device), lens=lens[:-1])
