@@ -94,7 +94,7 @@ class CLIPRetriever:
     def search_batch(self, queries: Sequence[str], alpha: float = 0.5, top_k: int = 10):
         if not 1 <= top_k <= MAX_TOP_K:
             raise ValueError(f"top_k must be in 1..{MAX_TOP_K}")
-        ids = self.tokenize_fn(list(queries)).to(self.store.image.device)
+        ids = self.tokenize_fn(list(queries))          # host ids: the engine takes the text lengths from them before the upload (no device sync)
         q = self.model.encode_text(ids, normalize=True)
         qp = engine.build_panel([q, q], _lib.SIDE_QUERY, ranking.PRECISION_TERMS[self.store.precision],
                                 part_scale=[alpha, 1.0 - alpha])
