@@ -74,6 +74,7 @@ struct kemr_model {
     int res_dtype = KEMR_F32;                       // storage type of the residual stream (KEMR_PREC_BF16_RES16: bf16)
     int fp8 = 0;                                    // bit 0: QKV on fp8 operands (KEMR_PREC_FP8), bit 1: fc1 too (KEMR_PREC_FP8_MLP)
     int resadd = 1;                                 // option "residual_fusion": residual add inside the out-proj / fc2 epilogues
+    int last_pooled = 1;                            // option "last_block_pooled_row": the last block's query path on the pooled row only
     // vision
     TowerW vis;
     const bf16_t* conv_w = nullptr;
@@ -136,6 +137,7 @@ extern "C" int kemr_model_create(const kemr_cfg* cfg, kemr_model** out) {
     if (!m) KEMR_FAIL(KEMR_ERR_NOMEM, "model_create: out of memory");
     m->cfg = *cfg;
     { const char* v = getenv("KEMR_RESADD"); const int e = (v && *v) ? atoi(v) : 1; m->resadd = e < 0 ? 0 : e > 2 ? 2 : e; }
+    { const char* v = getenv("KEMR_LAST_BLOCK_FULL"); m->last_pooled = (v && *v && atoi(v) != 0) ? 0 : 1; }
     m->grid = cfg->image_size / cfg->patch;
     m->patches = m->grid * m->grid;
     m->kpad = (int)round_up(3 * cfg->patch * cfg->patch, 64);
@@ -323,7 +325,17 @@ struct Workspace {
     bf16_t* delta2; // [Mp, W] bf16: output of the fc2 GEMM (MLP update), pending until the next block's ln_1 (or the tail)
     float* x32;     // [Mp, W] fp32 front-end rows of the vision tower (patch GEMM + cls, read by ln_pre): x itself for
                     // an fp32 stream, else the (then still unused) h | delta pair, which is contiguous and as large
+    // compact [Mc = ceil256(items), W] rows of the last block's pooled-row path (run_blocks)
+    int* pool_idx;  // [items] row of the class / end-of-text token
+    void* xc;       // residual-stream rows (x_dtype)
+    bf16_t *hc, *qc, *ac, *d1c, *d2c;   // LayerNorm output, query, attention output, the two pending updates
+    bf16_t* gc;     // [Mc, 4W] MLP hidden
 };
+
+size_t compact_bytes(int width, int items) {
+    const int64_t Mc = round_up((int64_t)items, 256);
+    return (size_t)(round_up((int64_t)items * 4, 256) + Mc * width * 4 + 5 * Mc * width * 2 + Mc * width * 8);
+}
 
 size_t ws_bytes_rows(int width, int64_t rows, int x_dtype) {
     const int64_t Mp = round_up(rows, 256);
@@ -337,8 +349,8 @@ size_t ws_bytes(int width, int tokens, int batch, int x_dtype) {
     return (size_t)(round_up(Mp * width * xb, 256) + 3 * round_up(Mp * width * 2, 256) + round_up(Mp * width * 8, 256));
 }
 
-int carve(Workspace& w, void* base, size_t bytes, int width, int64_t rows, int x_dtype) {
-    const size_t need = ws_bytes_rows(width, rows, x_dtype);
+int carve(Workspace& w, void* base, size_t bytes, int width, int64_t rows, int items, int x_dtype) {
+    const size_t need = ws_bytes_rows(width, rows, x_dtype) + compact_bytes(width, items);
     if (!base || bytes < need) KEMR_FAIL(KEMR_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", bytes, need);
     if ((uintptr_t)base % 256) KEMR_FAIL(KEMR_ERR_WORKSPACE, "workspace must be 256-byte aligned");
     const int64_t Mp = round_up(rows, 256);
@@ -348,7 +360,16 @@ int carve(Workspace& w, void* base, size_t bytes, int width, int64_t rows, int x
     w.h = (bf16_t*)p; p += round_up(Mp * width * 2, 256);
     w.delta = (bf16_t*)p; p += round_up(Mp * width * 2, 256);
     w.delta2 = (bf16_t*)p; p += round_up(Mp * width * 2, 256);
-    w.big = (bf16_t*)p;
+    w.big = (bf16_t*)p; p += round_up(Mp * width * 8, 256);
+    const int64_t Mc = round_up((int64_t)items, 256);
+    w.pool_idx = (int*)p; p += round_up((int64_t)items * 4, 256);
+    w.xc = p; p += Mc * width * 4;                     // (sized for an fp32 stream)
+    w.hc = (bf16_t*)p; p += Mc * width * 2;
+    w.qc = (bf16_t*)p; p += Mc * width * 2;
+    w.ac = (bf16_t*)p; p += Mc * width * 2;
+    w.d1c = (bf16_t*)p; p += Mc * width * 2;
+    w.d2c = (bf16_t*)p; p += Mc * width * 2;
+    w.gc = (bf16_t*)p;
     return KEMR_OK;
 }
 
@@ -369,8 +390,14 @@ int carve(Workspace& w, void* base, size_t bytes, int width, int64_t rows, int x
 //    at the HBM roofline with the matrix cores idle, and out-proj with 0.67 GB per launch is HBM-bound outright (122 us at best).
 // *pending = deltas left for the tail.
 // row_start / rows (text tower only): the token rows are packed, text i owning rows row_start[i] .. row_start[i + 1] - 1, `rows` in all.
+//
+// last_pooled (option "last_block_pooled_row", store-only epilogues, no fp8): only ONE row per item leaves a tower -- the class
+// token's (ln_post(x[:, 0]) @ proj) or the end-of-text token's -- so the LAST block computes K and V for every row (they feed that
+// row's attention) but the query, the attention output, out-proj, ln_2 and the MLP for the pooled rows alone: compact [items, W]
+// buffers, 2 of the block's 12 W^2 of GEMM work per token row instead of 12.  The pooled rows see the same arithmetic (their GEMMs
+// are smaller launches, routed to the skinny / 128-row kernels, with their summation order).  *compact = the tail reads xc / d1c / d2c.
 int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, int fp8, int want_resadd, hipStream_t s, bool* pending,
-               const int* row_start = nullptr, int rows = 0) {
+               const int* row_start = nullptr, int rows = 0, int last_pooled = 0, const int32_t* ids = nullptr, bool* compact = nullptr) {
     const int W = t.width, M = row_start ? rows : batch * t.tokens;
     const bool fq = fp8 & 1, f1 = fp8 & 2;          // LayerNorm output = A operand of QKV / fc1: e4m3 where that GEMM runs in fp8
     bool resadd = want_resadd >= (w.x_dtype == KEMR_BF16 ? 1 : 2) && M > 512 && W % 256 == 0;
@@ -383,8 +410,31 @@ int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, int f
         resadd = gemm256u_fits(a, 2, cs) && gemm256u_fits(b, 2, cs);
     }
     *pending = !resadd && t.layers > 0;
+    const bool pooled = last_pooled && compact && !resadd && !fp8 && t.layers > 0 && t.tokens <= 320;
+    if (compact) *compact = pooled;
+    if (pooled) KEMR_TRY(launch_pool_index(causal ? ids : nullptr, row_start, batch, t.tokens, w.pool_idx, s));
     for (int l = 0; l < t.layers; ++l) {
         const LayerW& L = t.layer[l];
+        if (pooled && l == t.layers - 1) {
+            KEMR_TRY(launch_layernorm(w.x, w.x_dtype, l ? w.delta : nullptr, l ? w.delta2 : nullptr, 1, L.ln1_g, L.ln1_b, w.h, M, W, KEMR_BF16, s));
+            GemmParams g{};
+            g.c_rows_padded = 1;
+            // K and V of every row: the weight rows W .. 3W - 1 of in_proj, into the columns W .. 3W - 1 of the qkv buffer
+            g.M = M; g.A = w.h; g.lda = W; g.W = L.wqkv + (size_t)W * W; g.ldw = W; g.bias = L.bqkv + W; g.C = w.big + W; g.ldc = 3 * W; g.N = 2 * W; g.K = W;
+            KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+            KEMR_TRY(launch_gather_pooled(w.x, w.x_dtype, w.h, w.pool_idx, batch, W, w.xc, w.hc, s));
+            g.M = batch; g.A = w.hc; g.W = L.wqkv; g.bias = L.bqkv; g.C = w.qc; g.ldc = W; g.N = W;
+            KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+            KEMR_TRY(launch_attention_pooled(w.qc, w.big, w.ac, w.pool_idx, row_start, batch, t.tokens, W, causal, s));
+            g.A = w.ac; g.W = L.wo; g.bias = L.bo; g.C = w.d1c;
+            KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+            KEMR_TRY(launch_layernorm(w.xc, w.x_dtype, w.d1c, nullptr, 0, L.ln2_g, L.ln2_b, w.hc, batch, W, KEMR_BF16, s));
+            g.A = w.hc; g.W = L.w1; g.bias = L.b1; g.C = w.gc; g.ldc = 4 * W; g.N = 4 * W;
+            KEMR_TRY(launch_gemm(g, EPI_BIAS_QGELU_BF16, s));
+            g.A = w.gc; g.lda = 4 * W; g.W = L.w2; g.ldw = 4 * W; g.bias = L.b2; g.C = w.d2c; g.ldc = W; g.N = W; g.K = 4 * W;
+            KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+            break;
+        }
         if (resadd) KEMR_TRY(launch_layernorm(w.x, w.x_dtype, nullptr, nullptr, 0, L.ln1_g, L.ln1_b, w.h, M, W, fq ? KEMR_FP8 : KEMR_BF16, s));
         else KEMR_TRY(launch_layernorm(w.x, w.x_dtype, l ? w.delta : nullptr, l ? w.delta2 : nullptr, 1, L.ln1_g, L.ln1_b, w.h, M, W, fq ? KEMR_FP8 : KEMR_BF16, s));
         GemmParams g{};
@@ -421,14 +471,15 @@ int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, int f
 
 extern "C" size_t kemr_workspace_bytes(const kemr_model* m, int tower, int batch) {
     if (!m || batch <= 0) return 0;
-    if (tower == KEMR_TOWER_VISION) return ws_bytes(m->cfg.v_width, m->patches + 1, batch, m->res_dtype);
-    if (tower == KEMR_TOWER_TEXT) return ws_bytes(m->cfg.t_width, m->cfg.ctx, batch, m->res_dtype);
+    if (tower == KEMR_TOWER_VISION) return ws_bytes(m->cfg.v_width, m->patches + 1, batch, m->res_dtype) + compact_bytes(m->cfg.v_width, batch);
+    if (tower == KEMR_TOWER_TEXT) return ws_bytes(m->cfg.t_width, m->cfg.ctx, batch, m->res_dtype) + compact_bytes(m->cfg.t_width, batch);
     return 0;
 }
 
 extern "C" size_t kemr_text_packed_workspace_bytes(const kemr_model* m, int rows, int batch) {
     if (!m || batch <= 0 || rows < batch) return 0;
-    return ws_bytes_rows(m->cfg.t_width, rows, m->res_dtype) + (size_t)round_up(((int64_t)batch + 1) * 4, 256);   // buffers + row_start
+    return ws_bytes_rows(m->cfg.t_width, rows, m->res_dtype) + compact_bytes(m->cfg.t_width, batch) +
+           (size_t)round_up(((int64_t)batch + 1) * 4, 256);                                        // buffers + pooled-row area + row_start
 }
 
 extern "C" int kemr_encode_image(kemr_model* m, const float* pixels_dev, int batch, float* out_dev, int normalize,
@@ -440,7 +491,7 @@ extern "C" int kemr_encode_image(kemr_model* m, const float* pixels_dev, int bat
     hipStream_t s = (hipStream_t)stream;
     const int W = m->cfg.v_width, T = m->patches + 1;
     Workspace w;
-    KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, (int64_t)batch * T, m->res_dtype));
+    KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, (int64_t)batch * T, batch, m->res_dtype));
     KEMR_TRY(launch_im2col(pixels_dev, w.big, batch, m->cfg.image_size, m->cfg.patch, m->kpad, s));
     GemmParams g{};
     g.A = w.big; g.lda = m->kpad; g.W = m->conv_w; g.ldw = m->kpad; g.bias = nullptr; g.C = w.x32; g.ldc = W;
@@ -448,9 +499,10 @@ extern "C" int kemr_encode_image(kemr_model* m, const float* pixels_dev, int bat
     KEMR_TRY(launch_gemm(g, EPI_PATCH_F32, s));
     KEMR_TRY(launch_cls_rows(w.x32, m->cls, m->vpos, batch, T, W, s));
     KEMR_TRY(launch_layernorm(w.x32, KEMR_F32, nullptr, nullptr, 0, m->lnpre_g, m->lnpre_b, w.x, batch * T, W, w.x_dtype, s));
-    bool vb = false;
-    KEMR_TRY(run_blocks(m->vis, w, batch, 0, m->fp8, m->resadd, s, &vb));
-    KEMR_TRY(launch_tail(w.x, w.x_dtype, vb ? w.delta : nullptr, vb ? w.delta2 : nullptr, nullptr, batch, T, W, m->lnpost_g, m->lnpost_b, m->vproj, m->cfg.embed_dim, normalize, out_dev, s));
+    bool vb = false, vc = false;
+    KEMR_TRY(run_blocks(m->vis, w, batch, 0, m->fp8, m->resadd, s, &vb, nullptr, 0, m->last_pooled, nullptr, &vc));
+    if (vc) KEMR_TRY(launch_tail(w.xc, w.x_dtype, w.d1c, w.d2c, nullptr, batch, 1, W, m->lnpost_g, m->lnpost_b, m->vproj, m->cfg.embed_dim, normalize, out_dev, s));
+    else KEMR_TRY(launch_tail(w.x, w.x_dtype, vb ? w.delta : nullptr, vb ? w.delta2 : nullptr, nullptr, batch, T, W, m->lnpost_g, m->lnpost_b, m->vproj, m->cfg.embed_dim, normalize, out_dev, s));
     return KEMR_OK;
 }
 
@@ -463,11 +515,12 @@ extern "C" int kemr_encode_text(kemr_model* m, const int32_t* ids_dev, int batch
     hipStream_t s = (hipStream_t)stream;
     const int W = m->cfg.t_width, T = m->cfg.ctx;
     Workspace w;
-    KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, (int64_t)batch * T, m->res_dtype));
+    KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, (int64_t)batch * T, batch, m->res_dtype));
     KEMR_TRY(launch_text_embed(ids_dev, m->tok, m->tpos, w.x, w.x_dtype, batch, T, W, m->cfg.vocab, s));
-    bool tb = false;
-    KEMR_TRY(run_blocks(m->txt, w, batch, 1, m->fp8, m->resadd, s, &tb));
-    KEMR_TRY(launch_tail(w.x, w.x_dtype, tb ? w.delta : nullptr, tb ? w.delta2 : nullptr, ids_dev, batch, T, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s));
+    bool tb = false, tc = false;
+    KEMR_TRY(run_blocks(m->txt, w, batch, 1, m->fp8, m->resadd, s, &tb, nullptr, 0, m->last_pooled, ids_dev, &tc));
+    if (tc) KEMR_TRY(launch_tail(w.xc, w.x_dtype, w.d1c, w.d2c, nullptr, batch, 1, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s));
+    else KEMR_TRY(launch_tail(w.x, w.x_dtype, tb ? w.delta : nullptr, tb ? w.delta2 : nullptr, ids_dev, batch, T, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s));
     return KEMR_OK;
 }
 
@@ -490,16 +543,17 @@ extern "C" int kemr_encode_text_packed(kemr_model* m, const int32_t* ids_dev, co
     hipStream_t s = (hipStream_t)stream;
     const int W = m->cfg.t_width, T = m->cfg.ctx;
     if (rows < batch || (int64_t)rows > (int64_t)batch * T) KEMR_FAIL(KEMR_ERR_INVALID, "encode_text_packed: %d rows for %d texts of 1 .. %d positions", rows, batch, T);
-    const size_t base_bytes = ws_bytes_rows(W, rows, m->res_dtype), need = base_bytes + (size_t)round_up(((int64_t)batch + 1) * 4, 256);
+    const size_t base_bytes = ws_bytes_rows(W, rows, m->res_dtype) + compact_bytes(W, batch), need = base_bytes + (size_t)round_up(((int64_t)batch + 1) * 4, 256);
     if (workspace_bytes < need) KEMR_FAIL(KEMR_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
     Workspace w;
-    KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, rows, m->res_dtype));
+    KEMR_TRY(carve(w, workspace_dev, workspace_bytes, W, rows, batch, m->res_dtype));
     int* row_start = (int*)((char*)workspace_dev + base_bytes);
     KEMR_TRY(launch_row_starts(lens_dev, batch, T, rows, row_start, s));
     KEMR_TRY(launch_text_embed(ids_dev, m->tok, m->tpos, w.x, w.x_dtype, batch, T, W, m->cfg.vocab, s, row_start, rows));
-    bool tb = false;
-    KEMR_TRY(run_blocks(m->txt, w, batch, 1, m->fp8, m->resadd, s, &tb, row_start, rows));
-    KEMR_TRY(launch_tail(w.x, w.x_dtype, tb ? w.delta : nullptr, tb ? w.delta2 : nullptr, ids_dev, batch, T, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s, row_start));
+    bool tb = false, tc = false;
+    KEMR_TRY(run_blocks(m->txt, w, batch, 1, m->fp8, m->resadd, s, &tb, row_start, rows, m->last_pooled, ids_dev, &tc));
+    if (tc) KEMR_TRY(launch_tail(w.xc, w.x_dtype, w.d1c, w.d2c, nullptr, batch, 1, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s));
+    else KEMR_TRY(launch_tail(w.x, w.x_dtype, tb ? w.delta : nullptr, tb ? w.delta2 : nullptr, ids_dev, batch, T, W, m->lnf_g, m->lnf_b, m->tproj, m->cfg.embed_dim, normalize, out_dev, s, row_start));
     return KEMR_OK;
 }
 
@@ -511,12 +565,18 @@ extern "C" int kemr_model_set_option(kemr_model* m, const char* key, int value) 
         m->resadd = value;
         return KEMR_OK;
     }
+    if (!strcmp(key, "last_block_pooled_row")) {
+        if (value < 0 || value > 1) KEMR_FAIL(KEMR_ERR_INVALID, "model_set_option(last_block_pooled_row): 0 or 1, got %d", value);
+        m->last_pooled = value;
+        return KEMR_OK;
+    }
     KEMR_FAIL(KEMR_ERR_INVALID, "model_set_option: unknown key '%s'", key);
 }
 
 extern "C" int kemr_model_get_option(const kemr_model* m, const char* key, int* value) {
     if (!m || !key || !value) KEMR_FAIL(KEMR_ERR_INVALID, "model_get_option: null argument");
     if (!strcmp(key, "residual_fusion")) { *value = m->resadd; return KEMR_OK; }
+    if (!strcmp(key, "last_block_pooled_row")) { *value = m->last_pooled; return KEMR_OK; }
     if (!strcmp(key, "precision_residual_bf16")) { *value = m->res_dtype == KEMR_BF16; return KEMR_OK; }
     KEMR_FAIL(KEMR_ERR_INVALID, "model_get_option: unknown key '%s'", key);
 }

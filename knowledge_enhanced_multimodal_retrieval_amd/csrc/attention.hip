@@ -877,6 +877,113 @@ int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int t, int width
     KEMR_FAIL(KEMR_ERR_INVALID, "attention: sequence length %d > 288 not supported", t);
 }
 
+// ---- the attention of the pooled row alone (last block of a tower) ----------------------------------------------------------------
+// Only one row per item leaves a tower (the class token / the end-of-text token), so in the LAST block only that row's query is
+// needed: one wave per (item, head) -- scores of the one query against the item's keys (eight lanes per key row, eight keys per
+// pass; bf16 products summed in fp32 like the MFMA does), softmax in fp32 with P rounded to bf16 and the row sum taken before the rounding (as in the
+// tile kernels), then out[d] = sum_j p_j v_j[d] with lane = (pair of d, key parity).  q: [items, width] compact rows (already scaled:
+// the 1/sqrt(64) lives in the packed q weights); k, v: the qkv buffer of the whole call (ld 3 * width); out: [items, width] compact.
+// Item b's keys are the rows key0[b] .. key0[b] + nkeys[b] - 1, taken from pool_idx / row_start:
+//   vision (causal = 0): all `tokens` rows from b * tokens;  text: the rows from the text's first up to the pooled one.
+__global__ __launch_bounds__(256) void attention_pooled_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ qkv,
+                                                               bf16_t* __restrict__ out, const int* __restrict__ pool_idx,
+                                                               const int* __restrict__ row_start, int items, int tokens, int width,
+                                                               int causal) {
+    constexpr float LOG2E = 1.4426950408889634f;
+    constexpr int MAXK = 320;
+    __shared__ float sp[4][MAXK];
+    const int heads = width >> 6, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wv;
+    if (item >= items * heads) return;                  // (no barrier below: a wave works on its own)
+    const int b = item / heads, h = item - b * heads;
+    const int r0 = row_start ? row_start[b] : b * tokens;
+    int nk = causal ? pool_idx[b] - r0 + 1 : tokens;
+    nk = nk < 1 ? 1 : (nk > MAXK ? MAXK : nk);
+    const size_t ld = 3 * (size_t)width;
+    // scores: eight lanes share a key row (lane & 7 = its 16-byte chunk: one 128-byte row per load instruction and key), eight keys
+    // per pass; the lane's eight products are summed in fp32, then the eight lanes of the key by shuffles
+    const int ck = lane & 7, kq = lane >> 3;
+    float qf[8];
+    {
+        const uint4 v = ((const uint4*)(q + (size_t)b * width + h * 64))[ck];
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            qf[2 * k] = bf16_to_f32((bf16_t)(w4[k] & 0xffff));
+            qf[2 * k + 1] = bf16_to_f32((bf16_t)(w4[k] >> 16));
+        }
+    }
+    const bf16_t* kbase = qkv + (size_t)r0 * ld + width + h * 64 + ck * 8;
+    const int npass = (nk + 7) >> 3;
+    for (int pss = 0; pss < npass; ++pss) {
+        const int j = pss * 8 + kq;
+        const int jc = j < nk ? j : nk - 1;
+        const uint4 v = *(const uint4*)(kbase + (size_t)jc * ld);
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s = fmaf(qf[2 * k], bf16_to_f32((bf16_t)(w4[k] & 0xffff)), s);
+            s = fmaf(qf[2 * k + 1], bf16_to_f32((bf16_t)(w4[k] >> 16)), s);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (ck == 0 && j < nk) sp[wv][j] = s;
+    }
+    // softmax over the wave's LDS row (written and read by this wave only; a wave's LDS accesses stay in order)
+    float sc[MAXK / 64];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int pss = 0; pss < MAXK / 64; ++pss) {
+        const int j = pss * 64 + lane;
+        sc[pss] = j < nk ? sp[wv][j] : -INFINITY;
+        mx = fmaxf(mx, sc[pss]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int pss = 0; pss < MAXK / 64; ++pss) {
+        const int j = pss * 64 + lane;
+        const float p = __builtin_amdgcn_exp2f((sc[pss] - mx) * LOG2E);         // -inf -> 0 beyond the keys
+        sum += p;
+        if (j < MAXK) sp[wv][j] = bf16_to_f32(f32_to_bf16(p));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    // (the wave's own LDS row: written and read by this wave only; the compiler orders LDS accesses of a wave by lgkmcnt)
+    const int dp = lane & 31, par = lane >> 5;
+    const bf16_t* vp = qkv + (size_t)r0 * ld + 2 * width + h * 64 + dp * 2;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll 4
+    for (int j = par; j < nk; j += 2) {
+        const uint32_t v = *(const uint32_t*)(vp + (size_t)j * ld);
+        const float p = sp[wv][j];
+        a0 = fmaf(p, bf16_to_f32((bf16_t)(v & 0xffff)), a0);
+        a1 = fmaf(p, bf16_to_f32((bf16_t)(v >> 16)), a1);
+    }
+    a0 += __shfl_xor(a0, 32);
+    a1 += __shfl_xor(a1, 32);
+    if (par == 0) {
+        const float inv = 1.0f / sum;
+        *(uint32_t*)(out + (size_t)b * width + h * 64 + dp * 2) = pack_bf16x2(a0 * inv, a1 * inv);
+    }
+}
+
+int launch_attention_pooled(const bf16_t* q, const bf16_t* qkv, bf16_t* out, const int* pool_idx, const int* row_start, int items,
+                            int tokens, int width, int causal, hipStream_t stream) {
+    if (items <= 0) return KEMR_OK;
+    if (width % 64 != 0 || tokens <= 0 || tokens > 320) KEMR_FAIL(KEMR_ERR_INVALID, "attention (pooled row): bad shape t=%d width=%d", tokens, width);
+    if (causal && !pool_idx) KEMR_FAIL(KEMR_ERR_INVALID, "attention (pooled row): the causal form needs the pooled positions");
+    ProfScope prof(PROF_ATTENTION, stream);
+    const long waves = (long)items * (width / 64);
+    hipLaunchKernelGGL(attention_pooled_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, q, qkv, out, pool_idx, row_start,
+                       items, tokens, width, causal);
+    KEMR_CHECK_LAUNCH("attention_pooled_kernel");
+    return KEMR_OK;
+}
+
 // Causal attention over items of different lengths packed one behind the other: item b = rows row_start[b] .. row_start[b + 1] - 1
 // (device array of batch + 1 ints), every length in 1 .. max_t.
 int launch_attention_packed(const bf16_t* qkv, bf16_t* out, const int* row_start, int batch, int max_t, int width, hipStream_t stream) {

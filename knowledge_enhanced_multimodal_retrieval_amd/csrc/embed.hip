@@ -153,6 +153,73 @@ int launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos
     return KEMR_OK;
 }
 
+// pool_idx[b] = the row of item b that leaves the tower: b * tokens (class token; ids == nullptr) or the first position of the
+// row maximum of its token ids (end-of-text token, torch.argmax semantics) -- inside the rows row_start gives the text when the
+// rows are packed (clamped to its last row, see kemr_encode_text_packed).  One wave per item.
+__global__ __launch_bounds__(256) void pool_index_kernel(const int32_t* __restrict__ ids, const int* __restrict__ row_start, int batch,
+                                                         int tokens, int* __restrict__ pool_idx) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= batch) return;
+    int best_t = 0;
+    if (ids) {
+        int best_v = INT_MIN;
+        best_t = INT_MAX;
+        for (int t = lane; t < tokens; t += 64) {
+            const int v = ids[(size_t)b * tokens + t];
+            if (v > best_v) { best_v = v; best_t = t; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int ov = __shfl_xor(best_v, o), ot = __shfl_xor(best_t, o);
+            if (ov > best_v || (ov == best_v && ot < best_t)) { best_v = ov; best_t = ot; }
+        }
+    }
+    if (lane == 0) {
+        int row = b * tokens + best_t;
+        if (row_start) {
+            const int r0 = row_start[b], len = row_start[b + 1] - r0;
+            row = r0 + (best_t < len ? best_t : len - 1);
+        }
+        pool_idx[b] = row;
+    }
+}
+
+int launch_pool_index(const int32_t* ids, const int* row_start, int batch, int tokens, int* pool_idx, hipStream_t stream) {
+    if (batch <= 0) return KEMR_OK;
+    ProfScope prof(PROF_OTHER, stream);
+    hipLaunchKernelGGL(pool_index_kernel, dim3((batch + 3) / 4), dim3(256), 0, stream, ids, row_start, batch, tokens, pool_idx);
+    KEMR_CHECK_LAUNCH("pool_index_kernel");
+    return KEMR_OK;
+}
+
+// The pooled rows of the residual stream x (fp32 or bf16) and of the LayerNorm output h (bf16), copied out into compact [batch, width]
+// buffers: what the last block's query path works on.  One workgroup per item.
+template <typename XT>
+__global__ __launch_bounds__(256) void gather_pooled_kernel(const XT* __restrict__ x, const bf16_t* __restrict__ h,
+                                                            const int* __restrict__ pool_idx, int width, XT* __restrict__ xc,
+                                                            bf16_t* __restrict__ hc) {
+    const int b = blockIdx.x;
+    const size_t src = (size_t)pool_idx[b] * width, dst = (size_t)b * width;
+    for (int i = threadIdx.x * 4; i < width; i += 1024) {
+        if constexpr (sizeof(XT) == 4) *(float4*)(xc + dst + i) = *(const float4*)(x + src + i);
+        else *(uint2*)(xc + dst + i) = *(const uint2*)(x + src + i);
+        *(uint2*)(hc + dst + i) = *(const uint2*)(h + src + i);
+    }
+}
+
+int launch_gather_pooled(const void* x, int x_dtype, const bf16_t* h, const int* pool_idx, int batch, int width, void* xc, bf16_t* hc,
+                         hipStream_t stream) {
+    if (batch <= 0) return KEMR_OK;
+    if (width % 4) KEMR_FAIL(KEMR_ERR_INVALID, "gather: width %d must be a multiple of 4", width);
+    ProfScope prof(PROF_OTHER, stream);
+    if (x_dtype == KEMR_BF16)
+        hipLaunchKernelGGL(gather_pooled_kernel<bf16_t>, dim3(batch), dim3(256), 0, stream, (const bf16_t*)x, h, pool_idx, width, (bf16_t*)xc, hc);
+    else
+        hipLaunchKernelGGL(gather_pooled_kernel<float>, dim3(batch), dim3(256), 0, stream, (const float*)x, h, pool_idx, width, (float*)xc, hc);
+    KEMR_CHECK_LAUNCH("gather_pooled_kernel");
+    return KEMR_OK;
+}
+
 // block-wide sum over 256 threads; red must hold 4 floats; all threads get the result
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);

@@ -92,6 +92,17 @@ class ClipEngine:
         residual streams too (nothing is rounded; slower)."""
         _lib.check(self._L.kemr_model_set_option(self._h, b"residual_fusion", int(level)), "model_set_option")
 
+    def set_last_block_pooled_row(self, on: bool) -> None:
+        """Option "last_block_pooled_row" of THIS model (default on): the last block of a tower computes its query path -- attention
+        output, out-proj, ln_2, MLP -- for the one row per item that leaves the tower (class / end-of-text token) instead of for all
+        of them; off = every row, as the reference does.  Store-only epilogues and non-fp8 precisions only."""
+        _lib.check(self._L.kemr_model_set_option(self._h, b"last_block_pooled_row", 1 if on else 0), "model_set_option")
+
+    def last_block_pooled_row(self) -> bool:
+        v = C.c_int(0)
+        _lib.check(self._L.kemr_model_get_option(self._h, b"last_block_pooled_row", C.byref(v)), "model_get_option")
+        return bool(v.value)
+
     def residual_fusion(self) -> int:
         """The option's value (0 / 1 / 2)."""
         v = C.c_int(0)

@@ -51,6 +51,9 @@ def test_model_options_and_debug_switches_are_separate():
     assert lib.kemr_model_get_option(h1, b"residual_fusion", C.byref(v)) == 0 and v.value == 0
     assert lib.kemr_model_get_option(h2, b"residual_fusion", C.byref(v)) == 0 and v.value == 1
     assert lib.kemr_model_set_option(h1, b"residual_fusion", 3) == -1 and lib.kemr_model_set_option(h1, b"nope", 1) == -1
+    assert lib.kemr_model_get_option(h1, b"last_block_pooled_row", C.byref(v)) == 0 and v.value == 1
+    assert lib.kemr_model_set_option(h1, b"last_block_pooled_row", 0) == 0 and lib.kemr_model_set_option(h1, b"last_block_pooled_row", 2) == -1
+    assert lib.kemr_model_get_option(h2, b"last_block_pooled_row", C.byref(v)) == 0 and v.value == 1
     lib.kemr_model_destroy(h1)
     lib.kemr_model_destroy(h2)
     before = {k: debug.get(k) for k in debug.KEYS}
@@ -86,7 +89,11 @@ def test_model_create_validates_config():
     n = lib.kemr_model_num_tensors(h)
     names = [lib.kemr_model_tensor_name(h, i).decode() for i in range(n)]
     assert n == 13 + 2 * 2 * 12 and "visual.transformer.resblocks.1.mlp.c_proj.weight" in names
-    assert lib.kemr_workspace_bytes(h, _lib.TOWER_VISION, 3) == 256 * 256 * 18    # 51 tokens -> 256 rows x 18 B x width (x f32, h, 2 deltas, 4W big)
+    # 51 tokens -> 256 rows x 18 B x width (x f32, h, 2 deltas, 4W big) + the last block's pooled-row area: 3 items -> 256 compact rows
+    # x 22 B x width (x f32, h, q, attention out, 2 deltas, 4W hidden) + 256 B of row indices
+    assert lib.kemr_workspace_bytes(h, _lib.TOWER_VISION, 3) == 256 * 256 * 18 + 256 * 256 * 22 + 256
+    assert lib.kemr_text_packed_workspace_bytes(h, 40, 3) == 256 * 256 * 18 + 256 * 256 * 22 + 256 + 256
+    assert lib.kemr_text_packed_workspace_bytes(h, 2, 3) == 0          # fewer rows than texts
     lib.kemr_model_destroy(h)
     for bad in (dict(v_width=200), dict(image_size=30), dict(embed_dim=0), dict(ctx=400), dict(patch=0)):
         h2 = C.c_void_p()
@@ -112,6 +119,7 @@ def test_load_tensor_is_strict_before_any_gpu_work():
     assert lib.kemr_model_finalize(h, _lib.PREC_BF16) == -2          # missing keys: refused before touching the GPU
     assert b"missing key" in lib.kemr_last_error()
     assert lib.kemr_encode_image(h, None, 1, None, 0, None, 0, None) == -1
+    assert lib.kemr_encode_text_packed(h, None, None, 1, 1, None, 0, None, 0, None) == -1
     lib.kemr_model_destroy(h)
 
 
