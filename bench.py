@@ -107,16 +107,20 @@ def gemm256u_census(arch, calls):
     QKV, out-proj, fc1, fc2 with A + W read once and C written once, all bf16 (the per-launch minimum the
     PMC traffic is compared with); with the residual add in the epilogue the out-proj and fc2 launches read their C tile too."""
     launches, nbytes = 0, 0.0
-    for kind, n, resadd, rows in calls:
+    for kind, n, resadd, rows, pooled in calls:
         tokens, w, layers = (arch.v_tokens, arch.v_width, arch.v_layers) if kind == "image" else (arch.ctx, arch.t_width, arch.t_layers)
         m = rows                                         # token rows of the call (texts: only the positions up to the end-of-text token)
         if m <= 512:
             continue                                     # the skinny kernel takes these
+        full = layers - 1 if pooled else layers          # pooled: the last block is ONE persistent launch (K, V: N = 2 W), the rest small kernels
         for nn, kk in ((3 * w, w), (w, w), (4 * w, w), (w, 4 * w)):
             # resadd: 0 = store-only bf16 C; 2 / 4 = the out-proj / fc2 launches read and write their C tile in place as bf16 / fp32
             c_bytes = 2.0 * m * nn if not (resadd and nn == w) else 2.0 * resadd * m * nn
-            nbytes += layers * (2.0 * (m * kk + nn * kk) + c_bytes)
-        launches += 4 * layers
+            nbytes += full * (2.0 * (m * kk + nn * kk) + c_bytes)
+        launches += 4 * full
+        if pooled:
+            nbytes += 2.0 * (m * w + 2 * w * w) + 2.0 * m * 2 * w
+            launches += 1
     return launches, nbytes
 
 
@@ -128,6 +132,16 @@ def gemm_flops_per_step_text(arch, batch):
 def gemm_flops_per_text_row(arch):
     """GEMM FLOPs one token row of the text tower costs (QKV, out-proj, fc1, fc2 of every layer)."""
     return 2.0 * arch.t_layers * (arch.t_width * 3 * arch.t_width + arch.t_width * arch.t_width + 2 * arch.t_width * 4 * arch.t_width)
+
+
+def tower_gemm_flops(width, layers, rows, items, pooled):
+    """GEMM FLOPs a tower call EXECUTES: 12 W^2 multiply-adds per token row and block (QKV 3, out-proj 1, fc1 4, fc2 4) -- and, when
+    the last block runs its query path on the pooled row only (option last_block_pooled_row), 2 W^2 per row (K, V) + 10 W^2 per
+    item in that block."""
+    unit = 2.0 * width * width
+    if pooled and layers > 0:
+        return unit * ((layers - 1) * 12.0 * rows + 2.0 * rows + 10.0 * items)
+    return unit * layers * 12.0 * rows
 
 
 def main():
@@ -227,17 +241,19 @@ def main():
             self.resadd = (2 if e.precision.endswith("res16") else 4) if resadd else 0      # bytes per in-place C element, census
             self.e, self.pending, self.images, self.texts, self.calls = e, 0, 0, 0, all_calls      # pooled texts; items encoded so far; the process-wide call list
             self.text_rows = 0                         # token rows the text calls computed
+            # whether this engine's last blocks run on the pooled row only (store-only epilogues, no fp8: api.hip run_blocks)
+            self.pooled = bool(e.last_block_pooled_row()) and not resadd and not e.precision.startswith("fp8")
 
         def step(self):
             a = self.e.encode_image(pixels, normalize=True)
-            self.calls.append(("image", B, self.resadd, B * arch.v_tokens))
+            self.calls.append(("image", B, self.resadd, B * arch.v_tokens, self.pooled))
             self.images += B
             self.pending += 2 * B
             p = self.pool
             self.e.pack_text = p.packed
             while self.pending >= p.group:
                 self.e.encode_text(p.ids, normalize=True, lens=p.lens)
-                self.calls.append(("text", p.group, self.resadd, p.rows(p.group)))
+                self.calls.append(("text", p.group, self.resadd, p.rows(p.group), self.pooled))
                 self.pending -= p.group
                 self.texts += p.group
                 self.text_rows += p.rows(p.group)
@@ -248,7 +264,7 @@ def main():
                 p = self.pool
                 self.e.pack_text = p.packed
                 self.e.encode_text(p.ids[:self.pending], normalize=True, lens=p.lens[:self.pending])
-                self.calls.append(("text", self.pending, self.resadd, p.rows(self.pending)))
+                self.calls.append(("text", self.pending, self.resadd, p.rows(self.pending), self.pooled))
                 self.texts += self.pending
                 self.text_rows += p.rows(self.pending)
                 self.pending = 0
@@ -256,8 +272,8 @@ def main():
         def check_outputs(self):            # the step's own items, for the oracle / cross-precision comparisons (untimed)
             pk = self.pool.packed
             self.e.pack_text = pk
-            self.calls += [("image", B, self.resadd, B * arch.v_tokens), ("text", B, self.resadd, int(q_lens.sum()) if pk else B * arch.ctx),
-                           ("text", B, self.resadd, int(t_lens.sum()) if pk else B * arch.ctx)]
+            self.calls += [("image", B, self.resadd, B * arch.v_tokens, self.pooled), ("text", B, self.resadd, int(q_lens.sum()) if pk else B * arch.ctx, self.pooled),
+                           ("text", B, self.resadd, int(t_lens.sum()) if pk else B * arch.ctx, self.pooled)]
             return (self.e.encode_image(pixels, normalize=True), self.e.encode_text(q_ids, normalize=True, lens=q_lens),
                     self.e.encode_text(t_ids, normalize=True, lens=t_lens))
 
@@ -297,7 +313,10 @@ def main():
     items = 3 * B * world * args.steps                       # images + query texts + target texts
     value = items / elapsed
     row_frac = float(pair_lens.sum()) / (2 * B * arch.ctx) if pack else 1.0      # share of the text token rows that is computed
-    flops_item_step = B * (arch.image_flops() + 2 * arch.text_flops() * row_frac)  # executed, not the full-context count
+    pooled_main = bool(eng.last_block_pooled_row()) and not resadd_on and not args.precision.startswith("fp8")
+    skip_v = (10.0 / 12.0) / arch.v_layers if pooled_main else 0.0                # share of a tower's work the pooled-row last block leaves out
+    skip_t = (10.0 / 12.0) / arch.t_layers if pooled_main else 0.0
+    flops_item_step = B * (arch.image_flops() * (1 - skip_v) + 2 * arch.text_flops() * row_frac * (1 - skip_t))  # executed, not the reference's count
     result = {
         "metric": "gallery images+texts encoded/sec (ViT-L/14) and 43k x Q sim+top-10 ms",
         "value": value, "unit": "items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -358,8 +377,7 @@ def main():
     # ------------------------------------------------------------------ roofline: per-class hipEvent timing
     L = _lib.lib()
     prof_steps = 10                                  # whole text groups only inside the profiled region; the rest drains after it
-    f_step, _ = gemm_flops_per_step(arch, B)
-    f_txt = gemm_flops_per_step_text(arch, B)
+    patch_flops = 2.0 * B * (arch.v_tokens - 1) * 3 * arch.patch * arch.patch * arch.v_width
 
     def profile_region(st):
         """10 steps of `st` under the library's per-class hipEvent timing -> (ms per class and step, GEMM launches per step, GEMM flops per step)."""
@@ -372,7 +390,9 @@ def main():
         _lib.check(L.kemr_profile_end(ms_, cnt_, 5))
         n_img, n_txt = st.images - i0, st.texts - t0_
         st.drain()
-        fl = ((f_step - f_txt) * n_img / B + gemm_flops_per_text_row(arch) * (st.text_rows - r0_)) / prof_steps      # of what the region actually launched
+        # GEMM FLOPs the region actually executed: whole image calls, the text calls by their token rows and items
+        fl = ((tower_gemm_flops(arch.v_width, arch.v_layers, B * arch.v_tokens, B, st.pooled) + patch_flops) * n_img / B +
+              tower_gemm_flops(arch.t_width, arch.t_layers, st.text_rows - r0_, n_txt, st.pooled)) / prof_steps
         return [m_ / prof_steps for m_ in ms_], cnt_[0] / prof_steps, fl
 
     ms, gemm_n, gemm_flops = profile_region(main_steps)
@@ -468,15 +488,21 @@ def main():
             result["roofline_sim"]["traffic"] = sj.get("bytes_per_launch")
             result["roofline_sim"]["traffic_source"] = {k: sj.get(k) for k in ("kernel", "profile", "round", "commit", "method")}
 
-    # ------------------------------------------------------------------ sub-result: the same steps with every text position computed
-    # The headline computes a text only up to its end-of-text token (the rows behind it cannot reach the pooled embedding: causal
-    # mask, reference pooling x[arange, text.argmax(-1)]); this leg runs the reference's full-context arithmetic -- 77 positions per
-    # text, 851 texts to a call -- on the same engine, and the embeddings of the two are compared.
+    # ------------------------------------------------------------------ sub-result: the same steps with every row computed
+    # The headline leaves out rows that cannot reach an output: a text is computed only up to its end-of-text token (causal mask,
+    # reference pooling x[arange, text.argmax(-1)]), and the last block of each tower runs its query path on the one row per item that
+    # leaves the tower.  This leg runs the reference's arithmetic in full -- 77 positions per text, 851 texts to a call, every row
+    # through every block -- on the same engine, and the embeddings of the two are compared.
     result["text_packing"] = {"enabled": bool(pack), "text_rows_computed_fraction": row_frac,
                               "mean_positions_per_text": float(pair_lens.float().mean()) if pack else float(arch.ctx), "context": arch.ctx,
                               "texts_per_call": text_group,
                               "lengths": "synthetic_ids: end-of-text token uniform in positions 8 .. 76 (unchanged since round 1)"}
-    if pack and not args.no_extras:
+    result["last_block_pooled_row"] = {"enabled": pooled_main, "tower_work_left_out_vision": skip_v, "tower_work_left_out_text": skip_t,
+                                       "what": "the last block of a tower computes K and V for every row and the query path (attention output, out-proj, "
+                                               "ln_2, MLP) for the class / end-of-text row only: the one row per item that leaves the tower"}
+    if (pack or pooled_main) and not args.no_extras:
+        pooled_option = eng.last_block_pooled_row()
+        eng.set_last_block_pooled_row(False)           # this leg: every position of every text, every row through every block
         s4 = Stepper(eng, resadd_on, make_pool(False))
         for _ in range(3):
             s4.step()
@@ -490,11 +516,14 @@ def main():
         barrier()
         dt = max_over_ranks(time.perf_counter() - t1)
         o4 = s4.check_outputs()
-        eng.pack_text = True
+        eng.pack_text = pack
+        eng.set_last_block_pooled_row(pooled_option)
         cos4 = [float(torch.nn.functional.cosine_similarity(a.double(), b.double()).min()) for a, b in zip(o4, out)]
-        result["text_packing"].update({"items_per_s_full_context": 3 * B * world * n4 / dt, "ms_per_step_full_context": 1e3 * dt / n4,
-                                       "speedup_vs_full_context": value / (3 * B * world * n4 / dt),
-                                       "min_cosine_vs_full_context_image_query_target": cos4})
+        result["reference_arithmetic"] = {"what": "the same steps with every text position and every row of every block computed (KEMR_TEXT_PACKED=0, "
+                                                  "last_block_pooled_row off): what the reference's model does; same engine, same run",
+                                          "items_per_s": 3 * B * world * n4 / dt, "ms_per_step": 1e3 * dt / n4, "steps": n4,
+                                          "headline_speedup_over_it": value / (3 * B * world * n4 / dt),
+                                          "min_cosine_headline_vs_it_image_query_target": cos4}
 
     # ------------------------------------------------------------------ sub-results: the same step at other precisions
     recall_bar = {}
