@@ -404,7 +404,9 @@ def main():
     # attached only to the configuration it was measured for.
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-    if os.path.exists(tpath) and args.model == "ViT-L/14" and B == 255 and args.precision == json.load(open(tpath)).get("precision", "bf16-res16") and resadd_on and args.gemm_variant == 0 and not args.text_group:
+    tj_ = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    if tj_ and args.model == "ViT-L/14" and B == 255 and args.precision == tj_.get("precision", "bf16-res16") and resadd_on == bool(tj_.get("residual_fusion_active", True)) and \
+            bool(pack) == bool(tj_.get("text_packed", False)) and pooled_main == bool(tj_.get("last_block_pooled_row", False)) and args.gemm_variant == 0 and not args.text_group:
         with open(tpath) as f:
             tj = json.load(f)
         traffic, traffic_source = tj.get("bytes_per_launch"), {k: tj.get(k) for k in ("profile", "round", "commit", "algorithmic_bytes_per_launch")}

@@ -104,7 +104,13 @@ int kemr_model_destroy(kemr_model* m);
  *   "residual_fusion"  calls of more than 512 token rows add the residual inside the out-proj / fc2 GEMM epilogues instead of
  *                      storing bf16 updates that the LayerNorms apply: 0 never; 1 (default; KEMR_RESADD in the environment at
  *                      create overrides) for bf16 residual streams (x is then rounded twice per layer instead of once); 2 for
- *                      fp32 residual streams as well (x += A.W^T + b in fp32, no update is rounded at all; slower). */
+ *                      fp32 residual streams as well (x += A.W^T + b in fp32, no update is rounded at all; slower).
+ *   "last_block_pooled_row"  1 (default; KEMR_LAST_BLOCK_FULL=1 in the environment at create makes it 0): one row per item leaves
+ *                      a tower -- the class token's (`ln_post(x[:, 0, :]) @ proj`) or the end-of-text token's -- so the LAST
+ *                      block computes K and V for every row but the query, attention output, out-proj, ln_2 and MLP for that
+ *                      row alone (2 instead of 12 W^2 of GEMM work per token row in that block).  The pooled rows see the same
+ *                      arithmetic in smaller launches.  Applies with store-only epilogues and non-fp8 precisions; 0 = every row
+ *                      through every block, as the reference computes it. */
 int kemr_model_set_option(kemr_model* m, const char* key, int value);
 int kemr_model_get_option(const kemr_model* m, const char* key, int* value);
 /* number of required tensor names; name i via kemr_model_tensor_name (for strict-load diagnostics) */
