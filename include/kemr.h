@@ -31,8 +31,10 @@ extern "C" {
 #endif
 
 /* 2: kemr_sim_workspace_bytes takes kdim, panels are allocated with ceil256(rows) rows (kemr_panel_build zero-fills up to
- *    256), kemr_model_set_option / kemr_model_get_option, the tools' switches live in kemr_debug.h (kemr_debug_set). */
-#define KEMR_ABI_VERSION 2
+ *    256), kemr_model_set_option / kemr_model_get_option, the tools' switches live in kemr_debug.h (kemr_debug_set).
+ * 3: kemr_encode_text_packed / kemr_text_packed_workspace_bytes, option "last_block_pooled_row"; kemr_workspace_bytes grows by the
+ *    last block's pooled-row area (callers that size their workspace with it need no change). */
+#define KEMR_ABI_VERSION 3
 
 typedef enum kemr_status {
     KEMR_OK = 0,

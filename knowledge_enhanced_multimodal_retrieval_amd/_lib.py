@@ -89,7 +89,7 @@ DEBUG_SIGNATURES = {
     "kemr_debug_sim_lists": (_i, [_vp, _i, _i, _i64, _i, _vp]),
     "kemr_debug_gemm_stamps": (_i, [_vp, _i]),
 }
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lock = threading.Lock()
 _lib = None
