@@ -223,6 +223,13 @@ int kemr_scores_dense(const void* q_panel_dev, int nq, const void* g_panel_dev, 
 int kemr_rank_dense(const float* scores_dev, int nq, int ng, int64_t ld, const int32_t* gt_idx_dev,
                     int32_t* ahead_dev, int k, float* top_scores_dev, int32_t* top_idx_dev, void* stream);
 
+/* Gate of the learned gated fusion heads in eval mode (reference src/clip/model/fusion_model.py: SimpleGatedFusion /
+ * SimpleGatedFusionWithBias `sigmoid((q * w).sum(1) + b)`, GatedFusionHead `Linear(d,128) -> ReLU -> Linear(128,1) -> Sigmoid`):
+ * out[r] = sigmoid(sum_c act(x[r,c] + pre_bias[c]) * w[c] + bias), act = ReLU when relu != 0 else identity; x fp32 [rows, cols]
+ * (the queries, or their Linear(d,128) image from the dense kernels), pre_bias fp32 [cols] or NULL, w fp32 [cols]. */
+int kemr_gate_rows(const float* x_dev, int rows, int cols, const float* pre_bias_dev, const float* w_dev, float bias, int relu,
+                   float* out_dev, void* stream);
+
 /* Learned "linear" fusion head in eval mode (reference src/clip/model/fusion_model.py:25-48):
  * out[i] = w1 . relu(W0 . [t2i[i], t2t[i]] + b0) + b1 over n score pairs (W0 fp32 [hidden,2], b0/w1 fp32 [hidden]). */
 int kemr_linear_head(const float* t2i_dev, const float* t2t_dev, int64_t n, const float* w0_dev, const float* b0_dev,

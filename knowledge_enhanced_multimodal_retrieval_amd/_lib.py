@@ -66,6 +66,7 @@ SIGNATURES = {
     "kemr_scores_dense": (_i, [_vp, _i, _vp, _i, _i64, _vp, _i64, _vp]),
     "kemr_rank_dense": (_i, [_vp, _i, _i, _i64, _vp, _vp, _i, _vp, _vp, _vp]),
     "kemr_linear_head": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _f, _i, _vp, _vp]),
+    "kemr_gate_rows": (_i, [_vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp]),
     "kemr_cross_attention_pairs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _vp]),
     "kemr_profile_begin": (_i, [_i]),
     "kemr_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i64), _i]),

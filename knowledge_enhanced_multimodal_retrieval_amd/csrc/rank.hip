@@ -172,9 +172,36 @@ __global__ __launch_bounds__(256) void cross_attn_pair_kernel(const float* __res
     }
 }
 
+// gate[r] = sigmoid(sum_c act(x[r, c] + pre[c]) * w[c] + bias), act = ReLU or identity: the last stage of the gated fusion heads
+// (one wave per row, fp32 throughout)
+__global__ __launch_bounds__(256) void gate_rows_kernel(const float* __restrict__ x, int rows, int cols, const float* __restrict__ pre,
+                                                        const float* __restrict__ w, float bias, int relu, float* __restrict__ out) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float* xr = x + (size_t)r * cols;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        float v = xr[c] + (pre ? pre[c] : 0.f);
+        if (relu) v = fmaxf(v, 0.f);
+        s = fmaf(v, w[c], s);
+    }
+    s = wave_sum(s) + bias;
+    if (lane == 0) out[r] = 1.0f / (1.0f + expf(-s));
+}
+
 }  // namespace kemr
 
 using namespace kemr;
+
+extern "C" int kemr_gate_rows(const float* x_dev, int rows, int cols, const float* pre_bias_dev, const float* w_dev, float bias, int relu,
+                              float* out_dev, void* stream) {
+    if (rows == 0) return KEMR_OK;
+    if (!x_dev || !w_dev || !out_dev || rows < 0 || cols < 1) KEMR_FAIL(KEMR_ERR_INVALID, "gate_rows: bad argument");
+    hipLaunchKernelGGL(gate_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x_dev, rows, cols, pre_bias_dev, w_dev,
+                       bias, relu, out_dev);
+    KEMR_CHECK_LAUNCH("gate_rows_kernel");
+    return KEMR_OK;
+}
 
 extern "C" int kemr_cross_attention_pairs(const float* st_i_dev, const float* st_t_dev, const float* p_i_dev,
                                           const float* p_t_dev, const float* c0_dev, const float* w2t_dev,

@@ -129,7 +129,7 @@ class FusionModel(nn.Module):
         q = ranking.to_device_f32(q)
         img, tgt = ranking.to_device_f32(img, q.device), ranking.to_device_f32(tgt, q.device)
         if self.fusion_type in _GATED:
-            g = h.to(q.device).eval().gate(q).reshape(-1).float()
+            g = self._gate(q)
             return [q, q], [img, tgt], None, [g, 1.0 - g]
         if self.fusion_type == "bilinear":
             h = h.to(q.device)
@@ -141,6 +141,24 @@ class FusionModel(nn.Module):
                 wq.append(engine.scores_dense(qp, wp))
             return wq, [img, tgt], [a, 1.0 - a], None
         raise NotImplementedError
+
+    def _gate(self, q: torch.Tensor) -> torch.Tensor:
+        """The gated heads' gate in eval mode, [N] fp32 on the GPU, through the library: Linear(d, 128) by the fp32x3 dense kernel,
+        everything behind it (bias, ReLU, the 128 -> 1 dot or the d -> 1 dot of the simple heads, sigmoid) in kemr_gate_rows; the
+        head's own ``gate()`` (torch) is what the tests compare it with."""
+        h = self.fusion_head.to(q.device).eval()
+        f32 = lambda t: t.detach().float().contiguous().to(q.device)
+        if hasattr(h, "gate_net"):
+            x, pre = self._linear(q, h.gate_net[0].weight), f32(h.gate_net[0].bias)
+            w, bias, relu = f32(h.gate_net[3].weight).reshape(-1), float(h.gate_net[3].bias.detach()), 1
+        else:
+            x, pre, w, bias, relu = q.float().contiguous(), None, f32(h.query_weight), float(h.bias.detach().reshape(-1)[0]), 0
+        out = torch.empty(x.shape[0], dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            _lib.check(_lib.lib().kemr_gate_rows(C.c_void_p(x.data_ptr()), x.shape[0], x.shape[1], C.c_void_p(pre.data_ptr()) if pre is not None else None,
+                                                 C.c_void_p(w.data_ptr()), bias, relu, C.c_void_p(out.data_ptr()),
+                                                 C.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)), "gate_rows")
+        return out
 
     @staticmethod
     def _linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -401,3 +401,27 @@ def test_sharded_gallery_single_process(device):
         parts_i.append(pi)
     ms, mi = engine.topk_merge(torch.stack(parts_s, 1), torch.stack(parts_i, 1), k)
     assert torch.equal(mi, i) and torch.equal(ms, s)
+
+
+@pytest.mark.parametrize("ft", ["gated", "simple_gated", "simple_gated_with_bias"])
+def test_gate_of_the_gated_heads_through_the_library(device, ft):
+    """FusionModel._gate (fp32x3 dense kernel for Linear(d, 128) + kemr_gate_rows) against the head's own torch gate() in fp64 on the
+    CPU, with non-trivial seeded parameters, d = 768 and a row count that is not a multiple of the kernel's four rows per workgroup."""
+    from src.clip.models import FusionModel
+
+    class NoClip(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+    torch.manual_seed(5)
+    fm = FusionModel(NoClip(), fusion_type=ft, embed_dim=768)
+    with torch.no_grad():
+        for p in fm.fusion_head.parameters():
+            p.copy_(torch.randn_like(p) * (0.2 if p.dim() > 1 else 0.5))
+    q = torch.nn.functional.normalize(torch.randn(1001, 768), dim=-1)
+    want = fm.fusion_head.double().eval().gate(q.double()).reshape(-1)
+    fm.fusion_head.float()
+    got = fm.to(device)._gate(q.to(device)).cpu().double()
+    assert got.shape == (1001,) and float((got - want).abs().max()) < 2e-6, float((got - want).abs().max())
+    assert float(got.min()) > 0 and float(got.max()) < 1 and float(got.std()) > 1e-3       # a gate, and not a constant one
