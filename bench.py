@@ -241,8 +241,8 @@ def main():
             self.resadd = (2 if e.precision.endswith("res16") else 4) if resadd else 0      # bytes per in-place C element, census
             self.e, self.pending, self.images, self.texts, self.calls = e, 0, 0, 0, all_calls      # pooled texts; items encoded so far; the process-wide call list
             self.text_rows = 0                         # token rows the text calls computed
-            # whether this engine's last blocks run on the pooled row only (store-only epilogues, no fp8: api.hip run_blocks)
-            self.pooled = bool(e.last_block_pooled_row()) and not resadd and not e.precision.startswith("fp8")
+            # whether this engine's last blocks run on the pooled row only (store-only epilogues, fc1 not on fp8: api.hip run_blocks)
+            self.pooled = bool(e.last_block_pooled_row()) and not resadd and e.precision != "fp8-mlp"
 
         def step(self):
             a = self.e.encode_image(pixels, normalize=True)
@@ -313,7 +313,7 @@ def main():
     items = 3 * B * world * args.steps                       # images + query texts + target texts
     value = items / elapsed
     row_frac = float(pair_lens.sum()) / (2 * B * arch.ctx) if pack else 1.0      # share of the text token rows that is computed
-    pooled_main = bool(eng.last_block_pooled_row()) and not resadd_on and not args.precision.startswith("fp8")
+    pooled_main = bool(eng.last_block_pooled_row()) and not resadd_on and args.precision != "fp8-mlp"
     skip_v = (10.0 / 12.0) / arch.v_layers if pooled_main else 0.0                # share of a tower's work the pooled-row last block leaves out
     skip_t = (10.0 / 12.0) / arch.t_layers if pooled_main else 0.0
     flops_item_step = B * (arch.image_flops() * (1 - skip_v) + 2 * arch.text_flops() * row_frac * (1 - skip_t))  # executed, not the reference's count

@@ -111,7 +111,7 @@ int kemr_model_destroy(kemr_model* m);
  *                      a tower -- the class token's (`ln_post(x[:, 0, :]) @ proj`) or the end-of-text token's -- so the LAST
  *                      block computes K and V for every row but the query, attention output, out-proj, ln_2 and MLP for that
  *                      row alone (2 instead of 12 W^2 of GEMM work per token row in that block).  The pooled rows see the same
- *                      arithmetic in smaller launches.  Applies with store-only epilogues and non-fp8 precisions; 0 = every row
+ *                      arithmetic in smaller launches.  Applies with store-only epilogues and fc1 on bf16 (not KEMR_PREC_FP8_MLP); 0 = every row
  *                      through every block, as the reference computes it. */
 int kemr_model_set_option(kemr_model* m, const char* key, int value);
 int kemr_model_get_option(const kemr_model* m, const char* key, int* value);

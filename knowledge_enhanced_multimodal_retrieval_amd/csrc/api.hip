@@ -391,7 +391,7 @@ int carve(Workspace& w, void* base, size_t bytes, int width, int64_t rows, int i
 // *pending = deltas left for the tail.
 // row_start / rows (text tower only): the token rows are packed, text i owning rows row_start[i] .. row_start[i + 1] - 1, `rows` in all.
 //
-// last_pooled (option "last_block_pooled_row", store-only epilogues, no fp8): only ONE row per item leaves a tower -- the class
+// last_pooled (option "last_block_pooled_row", store-only epilogues, fc1 not on fp8): only ONE row per item leaves a tower -- the class
 // token's (ln_post(x[:, 0]) @ proj) or the end-of-text token's -- so the LAST block computes K and V for every row (they feed that
 // row's attention) but the query, the attention output, out-proj, ln_2 and the MLP for the pooled rows alone: compact [items, W]
 // buffers, 2 of the block's 12 W^2 of GEMM work per token row instead of 12.  The pooled rows see the same arithmetic (their GEMMs
@@ -410,21 +410,24 @@ int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, int f
         resadd = gemm256u_fits(a, 2, cs) && gemm256u_fits(b, 2, cs);
     }
     *pending = !resadd && t.layers > 0;
-    const bool pooled = last_pooled && compact && !resadd && !fp8 && t.layers > 0 && t.tokens <= 320;
+    const bool pooled = last_pooled && compact && !resadd && !f1 && t.layers > 0 && t.tokens <= 320;
     if (compact) *compact = pooled;
     if (pooled) KEMR_TRY(launch_pool_index(causal ? ids : nullptr, row_start, batch, t.tokens, w.pool_idx, s));
     for (int l = 0; l < t.layers; ++l) {
         const LayerW& L = t.layer[l];
         if (pooled && l == t.layers - 1) {
-            KEMR_TRY(launch_layernorm(w.x, w.x_dtype, l ? w.delta : nullptr, l ? w.delta2 : nullptr, 1, L.ln1_g, L.ln1_b, w.h, M, W, KEMR_BF16, s));
+            KEMR_TRY(launch_layernorm(w.x, w.x_dtype, l ? w.delta : nullptr, l ? w.delta2 : nullptr, 1, L.ln1_g, L.ln1_b, w.h, M, W, fq ? KEMR_FP8 : KEMR_BF16, s));
             GemmParams g{};
             g.c_rows_padded = 1;
-            // K and V of every row: the weight rows W .. 3W - 1 of in_proj, into the columns W .. 3W - 1 of the qkv buffer
-            g.M = M; g.A = w.h; g.lda = W; g.W = L.wqkv + (size_t)W * W; g.ldw = W; g.bias = L.bqkv + W; g.C = w.big + W; g.ldc = 3 * W; g.N = 2 * W; g.K = W;
-            KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
-            KEMR_TRY(launch_gather_pooled(w.x, w.x_dtype, w.h, w.pool_idx, batch, W, w.xc, w.hc, s));
-            g.M = batch; g.A = w.hc; g.W = L.wqkv; g.bias = L.bqkv; g.C = w.qc; g.ldc = W; g.N = W;
-            KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+            // K and V of every row: the weight rows W .. 3W - 1 of in_proj, into the columns W .. 3W - 1 of the qkv buffer; then the query of
+            // the pooled rows from the first W weight rows (fq: both on e4m3 operands, like the QKV GEMM of the other blocks)
+            g.M = M; g.A = w.h; g.lda = W; g.ldw = W; g.bias = L.bqkv + W; g.C = w.big + W; g.ldc = 3 * W; g.N = 2 * W; g.K = W;
+            if (fq) { g.W = (const bf16_t*)(L.wqkv8 + (size_t)W * W); g.wscale = L.sqkv + W; KEMR_TRY(launch_gemm256u_fp8(g, EPI_BIAS_BF16, s)); }
+            else { g.W = L.wqkv + (size_t)W * W; KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s)); }
+            KEMR_TRY(launch_gather_pooled(w.x, w.x_dtype, w.h, fq ? KEMR_FP8 : KEMR_BF16, w.pool_idx, batch, W, w.xc, w.hc, s));
+            g.M = batch; g.A = w.hc; g.bias = L.bqkv; g.C = w.qc; g.ldc = W; g.N = W;
+            if (fq) { g.W = (const bf16_t*)L.wqkv8; g.wscale = L.sqkv; KEMR_TRY(launch_gemm256u_fp8(g, EPI_BIAS_BF16, s)); g.wscale = nullptr; }
+            else { g.W = L.wqkv; KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s)); }
             KEMR_TRY(launch_attention_pooled(w.qc, w.big, w.ac, w.pool_idx, row_start, batch, t.tokens, W, causal, s));
             g.A = w.ac; g.W = L.wo; g.bias = L.bo; g.C = w.d1c;
             KEMR_TRY(launch_gemm(g, EPI_BIAS_BF16, s));

@@ -185,8 +185,8 @@ int launch_cls_rows(float* x, const float* class_emb, const float* pos, int batc
 // the pooled row of every item (class token: ids == nullptr; else first argmax of the token ids, inside row_start's rows when packed)
 int launch_pool_index(const int32_t* ids, const int* row_start, int batch, int tokens, int* pool_idx, hipStream_t stream);
 // x[pool_idx[b]] -> xc[b], h[pool_idx[b]] -> hc[b]: compact copies of the pooled rows
-int launch_gather_pooled(const void* x, int x_dtype, const bf16_t* h, const int* pool_idx, int batch, int width, void* xc, bf16_t* hc,
-                         hipStream_t stream);
+int launch_gather_pooled(const void* x, int x_dtype, const void* h, int h_dtype /* KEMR_BF16 | KEMR_FP8 */, const int* pool_idx, int batch,
+                         int width, void* xc, void* hc, hipStream_t stream);
 // attention of the pooled row alone: q [items, width] compact, k / v from the call's qkv buffer, out [items, width] compact
 int launch_attention_pooled(const bf16_t* q, const bf16_t* qkv, bf16_t* out, const int* pool_idx, const int* row_start, int items,
                             int tokens, int width, int causal, hipStream_t stream);

@@ -195,27 +195,29 @@ int launch_pool_index(const int32_t* ids, const int* row_start, int batch, int t
 // The pooled rows of the residual stream x (fp32 or bf16) and of the LayerNorm output h (bf16), copied out into compact [batch, width]
 // buffers: what the last block's query path works on.  One workgroup per item.
 template <typename XT>
-__global__ __launch_bounds__(256) void gather_pooled_kernel(const XT* __restrict__ x, const bf16_t* __restrict__ h,
+__global__ __launch_bounds__(256) void gather_pooled_kernel(const XT* __restrict__ x, const void* __restrict__ h, int h_bytes,
                                                             const int* __restrict__ pool_idx, int width, XT* __restrict__ xc,
-                                                            bf16_t* __restrict__ hc) {
+                                                            void* __restrict__ hc) {
     const int b = blockIdx.x;
     const size_t src = (size_t)pool_idx[b] * width, dst = (size_t)b * width;
     for (int i = threadIdx.x * 4; i < width; i += 1024) {
         if constexpr (sizeof(XT) == 4) *(float4*)(xc + dst + i) = *(const float4*)(x + src + i);
         else *(uint2*)(xc + dst + i) = *(const uint2*)(x + src + i);
-        *(uint2*)(hc + dst + i) = *(const uint2*)(h + src + i);
+        if (h_bytes == 2) *(uint2*)((bf16_t*)hc + dst + i) = *(const uint2*)((const bf16_t*)h + src + i);
+        else *(uint32_t*)((uint8_t*)hc + dst + i) = *(const uint32_t*)((const uint8_t*)h + src + i);      // e4m3 rows
     }
 }
 
-int launch_gather_pooled(const void* x, int x_dtype, const bf16_t* h, const int* pool_idx, int batch, int width, void* xc, bf16_t* hc,
+int launch_gather_pooled(const void* x, int x_dtype, const void* h, int h_dtype, const int* pool_idx, int batch, int width, void* xc, void* hc,
                          hipStream_t stream) {
     if (batch <= 0) return KEMR_OK;
     if (width % 4) KEMR_FAIL(KEMR_ERR_INVALID, "gather: width %d must be a multiple of 4", width);
     ProfScope prof(PROF_OTHER, stream);
+    const int hb = h_dtype == KEMR_FP8 ? 1 : 2;
     if (x_dtype == KEMR_BF16)
-        hipLaunchKernelGGL(gather_pooled_kernel<bf16_t>, dim3(batch), dim3(256), 0, stream, (const bf16_t*)x, h, pool_idx, width, (bf16_t*)xc, hc);
+        hipLaunchKernelGGL(gather_pooled_kernel<bf16_t>, dim3(batch), dim3(256), 0, stream, (const bf16_t*)x, h, hb, pool_idx, width, (bf16_t*)xc, hc);
     else
-        hipLaunchKernelGGL(gather_pooled_kernel<float>, dim3(batch), dim3(256), 0, stream, (const float*)x, h, pool_idx, width, (float*)xc, hc);
+        hipLaunchKernelGGL(gather_pooled_kernel<float>, dim3(batch), dim3(256), 0, stream, (const float*)x, h, hb, pool_idx, width, (float*)xc, hc);
     KEMR_CHECK_LAUNCH("gather_pooled_kernel");
     return KEMR_OK;
 }

@@ -95,7 +95,8 @@ class ClipEngine:
     def set_last_block_pooled_row(self, on: bool) -> None:
         """Option "last_block_pooled_row" of THIS model (default on): the last block of a tower computes its query path -- attention
         output, out-proj, ln_2, MLP -- for the one row per item that leaves the tower (class / end-of-text token) instead of for all
-        of them; off = every row, as the reference does.  Store-only epilogues and non-fp8 precisions only."""
+        of them; off = every row, as the reference does.  Store-only epilogues only (not the bf16-stream modes' fused residual add), and
+        not with fc1 on fp8 ("fp8-mlp")."""
         _lib.check(self._L.kemr_model_set_option(self._h, b"last_block_pooled_row", 1 if on else 0), "model_set_option")
 
     def last_block_pooled_row(self) -> bool:

@@ -330,7 +330,7 @@ def test_text_rows_behind_the_eot_are_not_needed(device, name, ntxt, precision):
         eng.encode_text(ids.to(device), lens=lens[:-1])
 
 
-@pytest.mark.parametrize("precision", ["bf16", "bf16-res16"])
+@pytest.mark.parametrize("precision", ["bf16", "bf16-res16", "fp8", "fp8-mlp"])
 @pytest.mark.parametrize("name,nimg,ntxt", [("tiny", 9, 37), ("ViT-B/32", 70, 200), ("ViT-L/14", 20, 90)])
 def test_last_block_on_the_pooled_row_only(device, name, nimg, ntxt, precision):
     """Option last_block_pooled_row (default on): only the class / end-of-text row leaves a tower, so the LAST block computes K and V
@@ -360,9 +360,10 @@ def test_last_block_on_the_pooled_row_only(device, name, nimg, ntxt, precision):
     eng.pack_text = True
     d = [close(a, b) for a, b in zip(got[True], got[False])]
     print(f"{name} {precision}: pooled-row last block vs full, 1 - cos max: images {d[0]:.2e}, packed texts {d[1]:.2e}, full-context texts {d[2]:.2e}")
-    assert max(d) < 1e-4
-    if precision == "bf16-res16" and name != "tiny":
-        return                                   # (large calls of a bf16 stream add the residual in the GEMM epilogues: the option is idle there)
+    assert max(d) < (1e-4 if not precision.startswith("fp8") else 1e-3)    # (fp8: the pooled rows' query goes through another e4m3 launch shape)
+    if (precision == "bf16-res16" and name != "tiny") or precision == "fp8-mlp":
+        return                                   # (the option is idle: residual add in the GEMM epilogues / fc1 on fp8)
     ref_i = clip_ref.l2_normalize(clip_ref.encode_image(sd, oa, px[:6].cpu()))
     ref_t = clip_ref.l2_normalize(clip_ref.encode_text(sd, oa, ids[:12]))
-    assert close(got[True][0][:6].cpu(), ref_i) < COS_TOL and close(got[True][1][:12].cpu(), ref_t) < COS_TOL
+    tol = COS_TOL if precision != "fp8" else 5e-3
+    assert close(got[True][0][:6].cpu(), ref_i) < tol and close(got[True][1][:12].cpu(), ref_t) < tol
