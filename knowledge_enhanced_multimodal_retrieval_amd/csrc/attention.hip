@@ -861,7 +861,7 @@ static int launch_nt(const bf16_t* qkv, bf16_t* out, int batch, int t, int width
 int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int t, int width, int causal, hipStream_t stream) {
     if (batch <= 0) return KEMR_OK;
     if (width % 64 != 0 || t <= 0) KEMR_FAIL(KEMR_ERR_INVALID, "attention: bad shape t=%d width=%d", t, width);
-    if (batch > 65535) KEMR_FAIL(KEMR_ERR_INVALID, "attention: batch %d > 65535", batch);
+    if (batch > 65528) KEMR_FAIL(KEMR_ERR_INVALID, "attention: batch %d > 65528 (grid.y, rounded up to a multiple of 8)", batch);
     const int nt32 = (t + 31) / 32;
     switch (nt32) {
         case 1: return launch_nt<1>(qkv, out, batch, t, width, causal, stream);
@@ -990,7 +990,7 @@ int launch_attention_packed(const bf16_t* qkv, bf16_t* out, const int* row_start
     if (batch <= 0) return KEMR_OK;
     if (!row_start) KEMR_FAIL(KEMR_ERR_INVALID, "attention: packed rows need row_start");
     if (width % 64 != 0 || max_t <= 0) KEMR_FAIL(KEMR_ERR_INVALID, "attention: bad shape t=%d width=%d", max_t, width);
-    if (batch > 65535) KEMR_FAIL(KEMR_ERR_INVALID, "attention: batch %d > 65535", batch);
+    if (batch > 65528) KEMR_FAIL(KEMR_ERR_INVALID, "attention: batch %d > 65528 (grid.y, rounded up to a multiple of 8)", batch);
     switch ((max_t + 31) / 32) {
         case 1: return launch_nt<1>(qkv, out, batch, max_t, width, 1, stream, row_start);
         case 2: return launch_nt<2>(qkv, out, batch, max_t, width, 1, stream, row_start);

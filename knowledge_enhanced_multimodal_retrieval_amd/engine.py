@@ -208,14 +208,14 @@ class ClipEngine:
             s0, base = 0, 0
             while s0 < n:
                 s1 = s0 + 1
-                while s1 < n and csum[s1] - base <= TEXT_ROW_BUDGET and s1 - s0 < 65535:
+                while s1 < n and csum[s1] - base <= TEXT_ROW_BUDGET and s1 - s0 < 65528:
                     s1 += 1
                 rows = csum[s1 - 1] - base
                 need = int(self._L.kemr_text_packed_workspace_bytes(self._h, rows, s1 - s0))
                 ws = self._ws.get("text_packed")
                 if ws is None or ws.numel() < need:
                     ws = self._ws["text_packed"] = torch.empty(max(need, int(self._L.kemr_text_packed_workspace_bytes(
-                        self._h, min(TEXT_ROW_BUDGET, n * a.ctx), min(n, 65535)))), dtype=torch.uint8, device=self.device)
+                        self._h, min(TEXT_ROW_BUDGET, n * a.ctx), min(n, 65528)))), dtype=torch.uint8, device=self.device)
                 _lib.check(self._L.kemr_encode_text_packed(self._h, C.c_void_p(ids[s0:].data_ptr()), C.c_void_p(lens_dev[s0:].data_ptr()),
                                                            rows, s1 - s0, C.c_void_p(out[s0:].data_ptr()), 1 if normalize else 0,
                                                            C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(stream)), "encode_text_packed")
