@@ -322,3 +322,50 @@ def test_importing_the_loader_side_never_initialises_the_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=120)
     assert r.returncode == 0 and "clean" in r.stdout, r.stderr[-800:]
+
+
+def test_encode_dataset_groups_text_calls_by_token_rows(monkeypatch):
+    """evaluators.encode_dataset with a model that takes tokenizer-side lengths (host logic only: a CPU stand-in for the module):
+    text calls take as many (query, target) pairs as fill engine.TEXT_ROW_BUDGET token rows, every call gets the lengths of exactly its
+    texts (argmax + 1, queries then targets), every item is encoded once and the outputs come back in dataset order."""
+    from knowledge_enhanced_multimodal_retrieval_amd import engine, evaluators
+
+    arch = config.ARCHS["tiny"]
+    monkeypatch.setattr(engine, "TEXT_ROW_BUDGET", 120)
+    calls = []
+
+    class Fake(torch.nn.Module):
+        accepts_text_lengths = True
+
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+            self.arch = arch
+
+        def encode_image(self, images, normalize=False):
+            return images.reshape(images.shape[0], -1)[:, :4].float()
+
+        def encode_text(self, text, normalize=False, lens=None):
+            assert lens is not None and lens.numel() == text.shape[0] and not lens.is_cuda
+            assert torch.equal(lens, engine.text_lengths(text.cpu()))
+            calls.append((text.shape[0], int(lens.sum())))
+            return text[:, :4].float()                    # the first four ids identify the text
+
+    n = 57
+    ids_q, ids_t = clip_ref.synthetic_ids(clip_ref.ARCHS["tiny"], n, seed=1), clip_ref.synthetic_ids(clip_ref.ARCHS["tiny"], n, seed=2)
+    ids_q[:, 1], ids_t[:, 1] = torch.arange(n, dtype=torch.int32) + 1, torch.arange(n, dtype=torch.int32) + 1     # item number in position 1
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return n
+
+        def __getitem__(self, i):
+            return torch.full((3, 4, 4), float(i)), ("q", i), ("t", i), f"id{i}"
+
+    img, qry, tgt, uuids = evaluators.encode_dataset(Fake(), DS(), batch_size=8, seed=0, num_workers=0,
+                                                     tokenize_fn=lambda items: torch.stack([(ids_q if kind == "q" else ids_t)[i] for kind, i in items]))
+    assert uuids == [f"id{i}" for i in range(n)]
+    assert torch.equal(qry[:, 1].long(), torch.arange(n) + 1) and torch.equal(tgt[:, 1].long(), torch.arange(n) + 1)
+    assert torch.equal(qry, ids_q[:, :4].float()) and torch.equal(tgt, ids_t[:, :4].float()) and img.shape[0] == n
+    assert sum(c[0] for c in calls) == 2 * n and len(calls) > 3
+    assert all(rows <= 120 or texts == 2 for texts, rows in calls)        # a call stays inside the budget (one pair may exceed it alone)
