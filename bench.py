@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=255, help="gallery items per rank per step")
     ap.add_argument("--model", default="ViT-L/14")
-    ap.add_argument("--precision", default=_lib.DEFAULT_PRECISION, choices=["bf16", "bf16-res16", "fp8", "fp8-res16", "fp8-mlp"],
+    ap.add_argument("--precision", default=_lib.DEFAULT_PRECISION, choices=["bf16", "bf16-res16", "fp8", "fp8-res16", "fp8-mlp", "bf16-x24", "fp8-x24"],
                     help="bf16 operands with an fp32 (default, the product's default) or bf16 residual stream; fp8 variants")
     ap.add_argument("--image-slice", type=int, default=0, help="experiment: images per encoder launch (default: the engine's 255)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="A/B only: force a GEMM tile variant (0 = the library's choice)")
@@ -324,7 +324,7 @@ def main():
         "vs_baseline": None, "dtype": {"fp8": "fp8 (QKV) + bf16", "fp8-res16": "fp8 (QKV) + bf16", "fp8-mlp": "fp8 (QKV, fc1) + bf16"}.get(args.precision, "bf16"), "data": "synthetic",
         "config": {"workload": "CLIP ViT-L/14 zero-shot: 43k-gallery encode (1 image + query + target text per item, "
                                "224x224 / 77 tokens) + T2I top-10, BASELINE configs[1]",
-                   "model": args.model, "residual_stream": "bf16" if args.precision.endswith("res16") else "fp32", "batch_per_gpu": B, "text_group": text_group, "gallery": GALLERY, "parallelism": f"dp{world} (gallery sharded)",
+                   "model": args.model, "residual_stream": "bf16" if args.precision.endswith("res16") else ("fp24" if args.precision.endswith("x24") else "fp32"), "batch_per_gpu": B, "text_group": text_group, "gallery": GALLERY, "parallelism": f"dp{world} (gallery sharded)",
                    "items_timed": items, "rccl_ranks": rccl_ranks, "backend": (os.environ.get("KEMR_DIST_BACKEND", "nccl") if world > 1 else None),
                    "shard_bounds": shard_bounds},
         "images_per_s": B * world * args.steps / elapsed,
@@ -535,7 +535,7 @@ def main():
             recall_bar = json.load(f)
     if not args.no_extras and args.precision == _lib.DEFAULT_PRECISION:
         extras = {}
-        for prec in ("bf16-res16", "fp8", "fp8-res16"):
+        for prec in ("bf16-res16", "fp8", "fp8-res16", "bf16-x24", "fp8-x24"):
             e2 = engine.ClipEngine(arch, dev, precision=prec)
             e2.load_state_dict(random_weights(arch, seed=0))
             e2.pack_text = pack

@@ -26,7 +26,9 @@ PREC_FP8_RES16 = 5
 # oracle 3e-6 at the bench shape; Recall@10 of the stress test inside the fixed 0.2-point bar).  "bf16-res16" stores the stream as
 # bf16 (+ ~4 % items/s, 1 - cos 8e-5, Recall@10 drifts 0.5 points on that test): opt-in through KEMR_PRECISION, never the default.
 DEFAULT_PRECISION = "bf16"
-PRECISIONS = {"bf16": PREC_BF16, "bf16-res16": PREC_BF16_RES16, "fp8": PREC_FP8, "fp8-mlp": PREC_FP8_MLP, "fp8-res16": PREC_FP8_RES16}
+PRECISIONS = {"bf16": PREC_BF16, "bf16-res16": PREC_BF16_RES16, "fp8": PREC_FP8, "fp8-mlp": PREC_FP8_MLP, "fp8-res16": PREC_FP8_RES16,
+              # "-x24": the same arithmetic with the fp32 residual stream stored as 24-bit floats (model option residual_stream_24bit)
+              "bf16-x24": PREC_BF16, "fp8-x24": PREC_FP8}
 TOWER_VISION, TOWER_TEXT = 0, 1
 SIDE_QUERY, SIDE_GALLERY = 0, 1
 EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RESID_F32 = 0, 1, 2

@@ -75,6 +75,7 @@ struct kemr_model {
     int fp8 = 0;                                    // bit 0: QKV on fp8 operands (KEMR_PREC_FP8), bit 1: fc1 too (KEMR_PREC_FP8_MLP)
     int resadd = 1;                                 // option "residual_fusion": residual add inside the out-proj / fc2 epilogues
     int last_pooled = 1;                            // option "last_block_pooled_row": the last block's query path on the pooled row only
+    int stream24 = 0;                               // option "residual_stream_24bit" (before finalize): the fp32-class stream stored in 3 bytes
     // vision
     TowerW vis;
     const bf16_t* conv_w = nullptr;
@@ -138,6 +139,7 @@ extern "C" int kemr_model_create(const kemr_cfg* cfg, kemr_model** out) {
     m->cfg = *cfg;
     { const char* v = getenv("KEMR_RESADD"); const int e = (v && *v) ? atoi(v) : 1; m->resadd = e < 0 ? 0 : e > 2 ? 2 : e; }
     { const char* v = getenv("KEMR_LAST_BLOCK_FULL"); m->last_pooled = (v && *v && atoi(v) != 0) ? 0 : 1; }
+    { const char* v = getenv("KEMR_STREAM24"); m->stream24 = (v && *v && atoi(v) != 0) ? 1 : 0; }
     m->grid = cfg->image_size / cfg->patch;
     m->patches = m->grid * m->grid;
     m->kpad = (int)round_up(3 * cfg->patch * cfg->patch, 64);
@@ -301,6 +303,7 @@ extern "C" int kemr_model_finalize(kemr_model* m, int precision) {
 
     for (auto& kv : m->tensors) { std::vector<float>().swap(kv.second.data); kv.second.loaded = false; }
     m->res_dtype = (precision == KEMR_PREC_BF16_RES16 || precision == KEMR_PREC_FP8_RES16) ? KEMR_BF16 : KEMR_F32;
+    if (m->stream24 && m->res_dtype == KEMR_F32) m->res_dtype = KEMR_F24;      // option "residual_stream_24bit" (common.h f24_t)
     m->fp8 = fp8;
     m->finalized = true;
     return KEMR_OK;
@@ -339,13 +342,13 @@ size_t compact_bytes(int width, int items) {
 
 size_t ws_bytes_rows(int width, int64_t rows, int x_dtype) {
     const int64_t Mp = round_up(rows, 256);
-    const int xb = x_dtype == KEMR_BF16 ? 2 : 4;
+    const int xb = x_dtype == KEMR_BF16 ? 2 : (x_dtype == KEMR_F24 ? 3 : 4);
     return (size_t)(round_up(Mp * width * xb, 256) + 3 * round_up(Mp * width * 2, 256) + round_up(Mp * width * 8, 256));
 }
 
 size_t ws_bytes(int width, int tokens, int batch, int x_dtype) {
     const int64_t Mp = round_up((int64_t)batch * tokens, 256);
-    const int xb = x_dtype == KEMR_BF16 ? 2 : 4;
+    const int xb = x_dtype == KEMR_BF16 ? 2 : (x_dtype == KEMR_F24 ? 3 : 4);
     return (size_t)(round_up(Mp * width * xb, 256) + 3 * round_up(Mp * width * 2, 256) + round_up(Mp * width * 8, 256));
 }
 
@@ -355,8 +358,8 @@ int carve(Workspace& w, void* base, size_t bytes, int width, int64_t rows, int i
     if ((uintptr_t)base % 256) KEMR_FAIL(KEMR_ERR_WORKSPACE, "workspace must be 256-byte aligned");
     const int64_t Mp = round_up(rows, 256);
     char* p = (char*)base;
-    w.x = p; w.x_dtype = x_dtype; p += round_up(Mp * width * (x_dtype == KEMR_BF16 ? 2 : 4), 256);
-    w.x32 = x_dtype == KEMR_BF16 ? (float*)p : (float*)w.x;
+    w.x = p; w.x_dtype = x_dtype; p += round_up(Mp * width * (x_dtype == KEMR_BF16 ? 2 : (x_dtype == KEMR_F24 ? 3 : 4)), 256);
+    w.x32 = x_dtype == KEMR_F32 ? (float*)w.x : (float*)p;
     w.h = (bf16_t*)p; p += round_up(Mp * width * 2, 256);
     w.delta = (bf16_t*)p; p += round_up(Mp * width * 2, 256);
     w.delta2 = (bf16_t*)p; p += round_up(Mp * width * 2, 256);
@@ -400,7 +403,7 @@ int run_blocks(const TowerW& t, const Workspace& w, int batch, int causal, int f
                const int* row_start = nullptr, int rows = 0, int last_pooled = 0, const int32_t* ids = nullptr, bool* compact = nullptr) {
     const int W = t.width, M = row_start ? rows : batch * t.tokens;
     const bool fq = fp8 & 1, f1 = fp8 & 2;          // LayerNorm output = A operand of QKV / fc1: e4m3 where that GEMM runs in fp8
-    bool resadd = want_resadd >= (w.x_dtype == KEMR_BF16 ? 1 : 2) && M > 512 && W % 256 == 0;
+    bool resadd = want_resadd >= (w.x_dtype == KEMR_BF16 ? 1 : 2) && M > 512 && W % 256 == 0 && w.x_dtype != KEMR_F24;
     const int cs = w.x_dtype == KEMR_BF16 ? 2 : 4;
     const int epi_res = w.x_dtype == KEMR_BF16 ? EPI_BIAS_RESADD_BF16 : EPI_BIAS_RESID_F32;
     if (resadd) {
@@ -568,6 +571,12 @@ extern "C" int kemr_model_set_option(kemr_model* m, const char* key, int value) 
         m->resadd = value;
         return KEMR_OK;
     }
+    if (!strcmp(key, "residual_stream_24bit")) {
+        if (value < 0 || value > 1) KEMR_FAIL(KEMR_ERR_INVALID, "model_set_option(residual_stream_24bit): 0 or 1, got %d", value);
+        if (m->finalized) KEMR_FAIL(KEMR_ERR_STATE, "model_set_option(residual_stream_24bit): set it before kemr_model_finalize");
+        m->stream24 = value;
+        return KEMR_OK;
+    }
     if (!strcmp(key, "last_block_pooled_row")) {
         if (value < 0 || value > 1) KEMR_FAIL(KEMR_ERR_INVALID, "model_set_option(last_block_pooled_row): 0 or 1, got %d", value);
         m->last_pooled = value;
@@ -580,6 +589,7 @@ extern "C" int kemr_model_get_option(const kemr_model* m, const char* key, int* 
     if (!m || !key || !value) KEMR_FAIL(KEMR_ERR_INVALID, "model_get_option: null argument");
     if (!strcmp(key, "residual_fusion")) { *value = m->resadd; return KEMR_OK; }
     if (!strcmp(key, "last_block_pooled_row")) { *value = m->last_pooled; return KEMR_OK; }
+    if (!strcmp(key, "residual_stream_24bit")) { *value = m->finalized ? (m->res_dtype == KEMR_F24) : m->stream24; return KEMR_OK; }
     if (!strcmp(key, "precision_residual_bf16")) { *value = m->res_dtype == KEMR_BF16; return KEMR_OK; }
     KEMR_FAIL(KEMR_ERR_INVALID, "model_get_option: unknown key '%s'", key);
 }

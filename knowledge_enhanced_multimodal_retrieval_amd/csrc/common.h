@@ -53,6 +53,15 @@ static inline uint8_t f32_to_e4m3_host(float f) {
 
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+// Residual-stream rows as 24-bit floats (internal dtype code KEMR_F24): sign, 8 exponent bits, 15 mantissa bits = the upper three bytes
+// of the fp32, rounded to nearest.  A ROW of W elements is stored as its W bf16 upper halves followed by its W third bytes (3 W
+// bytes, so `f24_t* + row * W` is the row's address like for any other element type); 2^-16 relative per rounding, 128 x finer than
+// bf16, for 3 instead of 4 bytes per element in the LayerNorm passes, which are HBM-bound.
+constexpr int KEMR_F24 = 24;
+struct __attribute__((packed)) f24_t { uint8_t b[3]; };
+__device__ __forceinline__ float f24_to_f32(bf16_t hi, uint8_t lo) { return __uint_as_float(((uint32_t)hi << 16) | ((uint32_t)lo << 8)); }
+__device__ __forceinline__ uint32_t f32_to_f24_bits(float f) { return __float_as_uint(f) + 0x80u; }      // use bits 31..8
 // RNE; inputs on this path are finite (a NaN would come out as NaN-or-inf, MI355X_MICROARCH "Correctness boundaries")
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     uint32_t u = __float_as_uint(f);

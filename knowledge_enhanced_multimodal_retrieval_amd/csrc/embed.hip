@@ -131,6 +131,14 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
     const float4 p = ((const float4*)(pos + (size_t)t * width))[c4];
     if constexpr (sizeof(XT) == 4) {
         ((float4*)(x + (size_t)row * width))[c4] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    } else if constexpr (sizeof(XT) == 3) {            // 24-bit rows: W upper halves, then W third bytes (common.h f24_t)
+        const uint32_t e0 = f32_to_f24_bits(a.x + p.x), e1 = f32_to_f24_bits(a.y + p.y), e2 = f32_to_f24_bits(a.z + p.z), e3 = f32_to_f24_bits(a.w + p.w);
+        uint8_t* r = (uint8_t*)(x + (size_t)row * width);
+        uint2 h;
+        h.x = (e0 >> 16) | (e1 & 0xffff0000u);
+        h.y = (e2 >> 16) | (e3 & 0xffff0000u);
+        ((uint2*)r)[c4] = h;
+        ((uint32_t*)(r + 2 * (size_t)width))[c4] = ((e0 >> 8) & 0xff) | (e1 & 0xff00) | ((e2 << 8) & 0xff0000) | ((e3 << 16) & 0xff000000u);
     } else {
         uint2 pk;
         pk.x = pack_bf16x2(a.x + p.x, a.y + p.y);
@@ -147,6 +155,8 @@ int launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos
     const dim3 grid((unsigned)((total4 + 255) / 256));
     if (x_dtype == KEMR_BF16)
         hipLaunchKernelGGL(text_embed_kernel<bf16_t>, grid, dim3(256), 0, stream, ids, tok_emb, pos, (bf16_t*)x, ctx, width, vocab, total4, row_start, batch);
+    else if (x_dtype == KEMR_F24)
+        hipLaunchKernelGGL(text_embed_kernel<f24_t>, grid, dim3(256), 0, stream, ids, tok_emb, pos, (f24_t*)x, ctx, width, vocab, total4, row_start, batch);
     else
         hipLaunchKernelGGL(text_embed_kernel<float>, grid, dim3(256), 0, stream, ids, tok_emb, pos, (float*)x, ctx, width, vocab, total4, row_start, batch);
     KEMR_CHECK_LAUNCH("text_embed_kernel");
@@ -194,18 +204,15 @@ int launch_pool_index(const int32_t* ids, const int* row_start, int batch, int t
 
 // The pooled rows of the residual stream x (fp32 or bf16) and of the LayerNorm output h (bf16), copied out into compact [batch, width]
 // buffers: what the last block's query path works on.  One workgroup per item.
-template <typename XT>
-__global__ __launch_bounds__(256) void gather_pooled_kernel(const XT* __restrict__ x, const void* __restrict__ h, int h_bytes,
-                                                            const int* __restrict__ pool_idx, int width, XT* __restrict__ xc,
-                                                            void* __restrict__ hc) {
+// (rows copied as bytes: x_bytes = 4, 3 (24-bit rows, W upper halves + W third bytes) or 2 per element; h_bytes = 2 or 1 (e4m3))
+__global__ __launch_bounds__(256) void gather_pooled_kernel(const uint8_t* __restrict__ x, int x_bytes, const uint8_t* __restrict__ h, int h_bytes,
+                                                            const int* __restrict__ pool_idx, int width, uint8_t* __restrict__ xc,
+                                                            uint8_t* __restrict__ hc) {
     const int b = blockIdx.x;
-    const size_t src = (size_t)pool_idx[b] * width, dst = (size_t)b * width;
-    for (int i = threadIdx.x * 4; i < width; i += 1024) {
-        if constexpr (sizeof(XT) == 4) *(float4*)(xc + dst + i) = *(const float4*)(x + src + i);
-        else *(uint2*)(xc + dst + i) = *(const uint2*)(x + src + i);
-        if (h_bytes == 2) *(uint2*)((bf16_t*)hc + dst + i) = *(const uint2*)((const bf16_t*)h + src + i);
-        else *(uint32_t*)((uint8_t*)hc + dst + i) = *(const uint32_t*)((const uint8_t*)h + src + i);      // e4m3 rows
-    }
+    const size_t row = (size_t)pool_idx[b];
+    const int xb = width * x_bytes, hb = width * h_bytes;              // multiples of 4: width % 4 == 0
+    for (int i = threadIdx.x * 4; i < xb; i += 1024) *(uint32_t*)(xc + (size_t)b * xb + i) = *(const uint32_t*)(x + row * xb + i);
+    for (int i = threadIdx.x * 4; i < hb; i += 1024) *(uint32_t*)(hc + (size_t)b * hb + i) = *(const uint32_t*)(h + row * hb + i);
 }
 
 int launch_gather_pooled(const void* x, int x_dtype, const void* h, int h_dtype, const int* pool_idx, int batch, int width, void* xc, void* hc,
@@ -213,11 +220,9 @@ int launch_gather_pooled(const void* x, int x_dtype, const void* h, int h_dtype,
     if (batch <= 0) return KEMR_OK;
     if (width % 4) KEMR_FAIL(KEMR_ERR_INVALID, "gather: width %d must be a multiple of 4", width);
     ProfScope prof(PROF_OTHER, stream);
-    const int hb = h_dtype == KEMR_FP8 ? 1 : 2;
-    if (x_dtype == KEMR_BF16)
-        hipLaunchKernelGGL(gather_pooled_kernel<bf16_t>, dim3(batch), dim3(256), 0, stream, (const bf16_t*)x, h, hb, pool_idx, width, (bf16_t*)xc, hc);
-    else
-        hipLaunchKernelGGL(gather_pooled_kernel<float>, dim3(batch), dim3(256), 0, stream, (const float*)x, h, hb, pool_idx, width, (float*)xc, hc);
+    const int xb = x_dtype == KEMR_BF16 ? 2 : (x_dtype == KEMR_F24 ? 3 : 4), hb = h_dtype == KEMR_FP8 ? 1 : 2;
+    hipLaunchKernelGGL(gather_pooled_kernel, dim3(batch), dim3(256), 0, stream, (const uint8_t*)x, xb, (const uint8_t*)h, hb, pool_idx, width,
+                       (uint8_t*)xc, (uint8_t*)hc);
     KEMR_CHECK_LAUNCH("gather_pooled_kernel");
     return KEMR_OK;
 }
@@ -279,7 +284,9 @@ __global__ __launch_bounds__(256) void tail_proj_kernel(const XT* __restrict__ x
     float s = 0.f;
     for (int i = tid; i < width; i += 256) {           // pooled row (+ the pending residual update) into LDS
         float v;
-        if constexpr (sizeof(XT) == 4) v = xr[i]; else v = bf16_to_f32(xr[i]);
+        if constexpr (sizeof(XT) == 4) v = xr[i];
+        else if constexpr (sizeof(XT) == 3) v = f24_to_f32(((const bf16_t*)xr)[i], ((const uint8_t*)xr)[2 * (size_t)width + i]);
+        else v = bf16_to_f32(xr[i]);
         if (dr) v += bf16_to_f32(dr[i]);       // same order as the fused LayerNorm updates: (x + d1) + d2
         if (dr2) v += bf16_to_f32(dr2[i]);
         y[i] = v;
@@ -333,6 +340,8 @@ int launch_tail(const void* x, int x_dtype, const bf16_t* delta, const bf16_t* d
     const dim3 grid((d + 63) / 64, batch);
     if (x_dtype == KEMR_BF16)
         hipLaunchKernelGGL(tail_proj_kernel<bf16_t>, grid, dim3(256), smem, stream, (const bf16_t*)x, delta, delta2, ids, tokens, width, gamma, beta, proj, d, out, row_start);
+    else if (x_dtype == KEMR_F24)
+        hipLaunchKernelGGL(tail_proj_kernel<f24_t>, grid, dim3(256), smem, stream, (const f24_t*)x, delta, delta2, ids, tokens, width, gamma, beta, proj, d, out, row_start);
     else
         hipLaunchKernelGGL(tail_proj_kernel<float>, grid, dim3(256), smem, stream, (const float*)x, delta, delta2, ids, tokens, width, gamma, beta, proj, d, out, row_start);
     KEMR_CHECK_LAUNCH("tail_proj_kernel");

@@ -13,14 +13,30 @@ namespace kemr {
 //                              stays pending and is added for good, together with the MLP delta, by the next ln_1
 // (one x write per block instead of two; the sums are formed in the same order as two separate updates, so an fp32
 // stream holds bit-identical values).
-__device__ __forceinline__ float4 load_row4(const float* r, int i) { return ((const float4*)r)[i]; }
-__device__ __forceinline__ float4 load_row4(const bf16_t* r, int i) {
+// (W = the row's width in elements; only the 24-bit rows need it: their third bytes sit behind the W upper halves)
+__device__ __forceinline__ float4 load_row4(const float* r, int i, int) { return ((const float4*)r)[i]; }
+__device__ __forceinline__ float4 load_row4(const f24_t* r, int i, int W) {
+    const uint2 h = ((const uint2*)r)[i];
+    const uint32_t l = ((const uint32_t*)((const uint8_t*)r + 2 * (size_t)W))[i];
+    return make_float4(f24_to_f32((bf16_t)(h.x & 0xffff), (uint8_t)l), f24_to_f32((bf16_t)(h.x >> 16), (uint8_t)(l >> 8)),
+                       f24_to_f32((bf16_t)(h.y & 0xffff), (uint8_t)(l >> 16)), f24_to_f32((bf16_t)(h.y >> 16), (uint8_t)(l >> 24)));
+}
+__device__ __forceinline__ float4 load_row4(const bf16_t* r, int i, int) {
     const uint2 d = ((const uint2*)r)[i];
     return make_float4(bf16_to_f32((bf16_t)(d.x & 0xffff)), bf16_to_f32((bf16_t)(d.x >> 16)),
                        bf16_to_f32((bf16_t)(d.y & 0xffff)), bf16_to_f32((bf16_t)(d.y >> 16)));
 }
-__device__ __forceinline__ void store_row4(float* r, int i, float4 v) { ((float4*)r)[i] = v; }
-__device__ __forceinline__ void store_row4(bf16_t* r, int i, float4 v) {
+__device__ __forceinline__ void store_row4(float* r, int i, float4 v, int) { ((float4*)r)[i] = v; }
+__device__ __forceinline__ void store_row4(f24_t* r, int i, float4 v, int W) {
+    const uint32_t a = f32_to_f24_bits(v.x), b = f32_to_f24_bits(v.y), c = f32_to_f24_bits(v.z), d = f32_to_f24_bits(v.w);
+    uint2 h;
+    h.x = (a >> 16) | (b & 0xffff0000u);
+    h.y = (c >> 16) | (d & 0xffff0000u);
+    ((uint2*)r)[i] = h;
+    ((uint32_t*)((uint8_t*)r + 2 * (size_t)W))[i] = ((a >> 8) & 0xff) | (b & 0xff00) | ((c << 8) & 0xff0000) | ((d << 16) & 0xff000000u);
+}
+// (a row that was just stored as 24-bit floats is read back rounded: the statistics of ln_1 use the fp32 sum, like for a bf16 stream)
+__device__ __forceinline__ void store_row4(bf16_t* r, int i, float4 v, int) {
     uint2 pk;
     pk.x = pack_bf16x2(v.x, v.y);
     pk.y = pack_bf16x2(v.z, v.w);
@@ -28,7 +44,7 @@ __device__ __forceinline__ void store_row4(bf16_t* r, int i, float4 v) {
 }
 
 struct fp8_t { uint8_t v; };          // output tag: OCP e4m3 bytes (the A operand of the fp8 GEMMs), unit scale, saturating
-__device__ __forceinline__ void store_row4(fp8_t* r, int i, float4 v) {
+__device__ __forceinline__ void store_row4(fp8_t* r, int i, float4 v, int) {
     const float lim = 448.f;
     int pk = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v.x, -lim, lim), __builtin_amdgcn_fmed3f(v.y, -lim, lim), 0, false);
     pk = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v.z, -lim, lim), __builtin_amdgcn_fmed3f(v.w, -lim, lim), pk, true);
@@ -48,15 +64,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(XT* x, const bf16_t* __r
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        v[i] = load_row4(xr, i * 64 + lane);
+        v[i] = load_row4(xr, i * 64 + lane, W);
         if constexpr (MODE != 0) {
-            const float4 d = load_row4(delta + (size_t)row * W, i * 64 + lane);
+            const float4 d = load_row4(delta + (size_t)row * W, i * 64 + lane, W);
             v[i].x += d.x; v[i].y += d.y; v[i].z += d.z; v[i].w += d.w;
             if (MODE == 1 && delta2) {               // wave-uniform
-                const float4 e = load_row4(delta2 + (size_t)row * W, i * 64 + lane);
+                const float4 e = load_row4(delta2 + (size_t)row * W, i * 64 + lane, W);
                 v[i].x += e.x; v[i].y += e.y; v[i].z += e.z; v[i].w += e.w;
             }
-            if constexpr (MODE == 1) store_row4(xr, i * 64 + lane, v[i]);   // a bf16 stream rounds here; the statistics use the fp32 sum
+            if constexpr (MODE == 1) store_row4(xr, i * 64 + lane, v[i], W);   // a bf16 stream rounds here; the statistics use the fp32 sum
         }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
@@ -77,7 +93,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(XT* x, const bf16_t* __r
         o.y = v[i].y * rstd * g.y + b.y;
         o.z = v[i].z * rstd * g.z + b.z;
         o.w = v[i].w * rstd * g.w + b.w;
-        store_row4(y + (size_t)row * W, i * 64 + lane, o);
+        store_row4(y + (size_t)row * W, i * 64 + lane, o, W);
     }
 }
 
@@ -98,7 +114,12 @@ static int launch_nv(XT* x, const bf16_t* d1, const bf16_t* d2, int writeback, c
         hipLaunchKernelGGL((layernorm_kernel<NV, XT, bf16_t, 2>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (bf16_t*)y, rows, 1e-5f);
     else if (out_dtype == KEMR_BF16)
         hipLaunchKernelGGL((layernorm_kernel<NV, XT, bf16_t, 0>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (bf16_t*)y, rows, 1e-5f);
-    else
+    else if (out_dtype == KEMR_F24) {                  // ln_pre into a 24-bit stream: fp32 rows in only
+        if constexpr (sizeof(XT) == 4)
+            hipLaunchKernelGGL((layernorm_kernel<NV, XT, f24_t, 0>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (f24_t*)y, rows, 1e-5f);
+        else
+            KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: 24-bit output rows need fp32 input rows");
+    } else
         hipLaunchKernelGGL((layernorm_kernel<NV, XT, float, 0>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (float*)y, rows, 1e-5f);
     KEMR_CHECK_LAUNCH("layernorm_kernel");
     return KEMR_OK;
@@ -122,11 +143,12 @@ static int launch_xt(XT* x, const bf16_t* d1, const bf16_t* d2, int writeback, c
 int launch_layernorm(void* x, int x_dtype, const bf16_t* delta, const bf16_t* delta2, int writeback, const float* gamma,
                      const float* beta, void* y, int rows, int width, int out_dtype, hipStream_t stream) {
     if (rows <= 0) return KEMR_OK;
-    if (out_dtype != KEMR_BF16 && out_dtype != KEMR_F32 && out_dtype != KEMR_FP8) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: bad out dtype %d", out_dtype);
-    if (x_dtype != KEMR_BF16 && x_dtype != KEMR_F32) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: bad row dtype %d", x_dtype);
-    if (delta && out_dtype == KEMR_F32) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: the residual forms write bf16 or fp8");
+    if (out_dtype != KEMR_BF16 && out_dtype != KEMR_F32 && out_dtype != KEMR_FP8 && out_dtype != KEMR_F24) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: bad out dtype %d", out_dtype);
+    if (x_dtype != KEMR_BF16 && x_dtype != KEMR_F32 && x_dtype != KEMR_F24) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: bad row dtype %d", x_dtype);
+    if (delta && (out_dtype == KEMR_F32 || out_dtype == KEMR_F24)) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: the residual forms write bf16 or fp8");
     if (delta2 && !(delta && writeback)) KEMR_FAIL(KEMR_ERR_INVALID, "layernorm: a second delta needs the first one and writeback");
     if (x_dtype == KEMR_BF16) return launch_xt((bf16_t*)x, delta, delta2, writeback, gamma, beta, y, rows, width, out_dtype, stream);
+    if (x_dtype == KEMR_F24) return launch_xt((f24_t*)x, delta, delta2, writeback, gamma, beta, y, rows, width, out_dtype, stream);
     return launch_xt((float*)x, delta, delta2, writeback, gamma, beta, y, rows, width, out_dtype, stream);
 }
 

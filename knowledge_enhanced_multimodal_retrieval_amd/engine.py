@@ -60,8 +60,9 @@ class ClipEngine:
 
     def __init__(self, arch: ClipArch, device: torch.device | str = "cuda:0", precision: str = _lib.DEFAULT_PRECISION):
         """precision: "bf16" (default: bf16 operands, fp32 accumulation, fp32 residual stream), "bf16-res16" (bf16 residual
-        stream, opt-in), "fp8" (QKV GEMMs on fp8 operands, BASELINE config 5), "fp8-res16" or "fp8-mlp" (fc1 too); see
-        kemr_precision in include/kemr.h."""
+        stream, opt-in), "fp8" (QKV GEMMs on fp8 operands, BASELINE config 5), "fp8-res16" or "fp8-mlp" (fc1 too); "bf16-x24" /
+        "fp8-x24": bf16 / fp8 with the fp32 residual stream stored as 24-bit floats (opt-in; model option residual_stream_24bit).
+        See kemr_precision in include/kemr.h."""
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
         self.precision = precision
@@ -128,6 +129,8 @@ class ClipEngine:
             shape = (C.c_int64 * max(host.dim(), 1))(*host.shape)
             _lib.check(self._L.kemr_model_load_tensor(self._h, name.encode(), C.c_void_p(host.data_ptr()), _lib.KEMR_F32,
                                                       shape, host.dim()), f"load_tensor({name})")
+        if self.precision.endswith("-x24"):
+            _lib.check(self._L.kemr_model_set_option(self._h, b"residual_stream_24bit", 1), "model_set_option")
         with torch.cuda.device(self.device):
             _lib.check(self._L.kemr_model_finalize(self._h, _lib.PRECISIONS[self.precision]), "model_finalize")
         self.ready = True
