@@ -113,6 +113,8 @@ class ClipEngine:
 
     def residual_fusion_active(self) -> bool:
         """Whether large calls of THIS engine add the residual inside the GEMM epilogues (option and stream type together)."""
+        if self.precision.endswith("-x24"):
+            return False                                   # 24-bit stream rows: store-only epilogues, whatever the option says
         return self.residual_fusion() >= (1 if self.precision.endswith("res16") else 2)
 
     # ------------------------------------------------------------------ weights
@@ -481,6 +483,38 @@ def op_layernorm_rows(x: torch.Tensor, delta: Optional[torch.Tensor], gamma: tor
                                             C.c_void_p(y.data_ptr()), rows, width,
                                             _lib.KEMR_FP8 if out_fp8 else (_lib.KEMR_BF16 if out_bf16 else _lib.KEMR_F32),
                                             C.c_void_p(_stream_ptr(x.device))), "op_layernorm_rows")
+    return y
+
+
+def pack_f24_rows(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [rows, W] -> the library's 24-bit-float rows (csrc/common.h f24_t): uint8 [rows, 3 W], a row = its W bf16 upper halves
+    (little endian) followed by its W third bytes; round to nearest on the 24 kept bits.  Tests / tools."""
+    bits = (x.contiguous().view(torch.int32).to(torch.int64) & 0xffffffff) + 0x80
+    hi = ((bits >> 16) & 0xffff)
+    lo = ((bits >> 8) & 0xff).to(torch.uint8)
+    hi_bytes = torch.stack([(hi & 0xff).to(torch.uint8), (hi >> 8).to(torch.uint8)], dim=-1).reshape(x.shape[0], -1)
+    return torch.cat([hi_bytes, lo], dim=1).contiguous()
+
+
+def unpack_f24_rows(rows24: torch.Tensor, width: int) -> torch.Tensor:
+    """The inverse of pack_f24_rows (exact): uint8 [rows, 3 W] -> fp32 [rows, W]."""
+    hb = rows24[:, :2 * width].reshape(-1, width, 2).to(torch.int64)
+    lo = rows24[:, 2 * width:].to(torch.int64)
+    bits = (hb[..., 1] << 24) | (hb[..., 0] << 16) | (lo << 8)
+    bits = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits)
+    return bits.to(torch.int32).view(torch.float32)
+
+
+def op_layernorm_rows_f24(x24: torch.Tensor, width: int, delta: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+                          delta2: Optional[torch.Tensor] = None, writeback: bool = True) -> torch.Tensor:
+    """op_layernorm_rows on 24-bit-float rows (pack_f24_rows layout, updated in place with `writeback`); bf16 output."""
+    L = _lib.lib()
+    rows = x24.shape[0]
+    y = torch.empty((rows, width), dtype=torch.bfloat16, device=x24.device)
+    with torch.cuda.device(x24.device):
+        _lib.check(L.kemr_op_layernorm_rows(C.c_void_p(x24.data_ptr()), 24, _opt_ptr(delta), _opt_ptr(delta2), 1 if writeback else 0,
+                                            C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()), C.c_void_p(y.data_ptr()), rows, width,
+                                            _lib.KEMR_BF16, C.c_void_p(_stream_ptr(x24.device))), "op_layernorm_rows")
     return y
 
 

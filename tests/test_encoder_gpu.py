@@ -173,7 +173,7 @@ def test_fp8_encoders_match_oracle(device, name, nimg, ntxt, precision, tol):
     assert float((1 - ci).max()) < tol and float((1 - ct).max()) < tol
 
 
-@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("precision", ["bf16", "bf16-res16"])          # (a 24-bit stream has no in-place epilogue: the option is idle there)
 def test_residual_fusion_switch(device, precision):
     """Option "residual_fusion" (per model): residual add inside the out-proj / fc2 epilogues (default) against the store-only
     epilogues + LayerNorm updates: both inside the path's bar against the oracle, close to each other, the switch really

@@ -548,3 +548,40 @@ def test_attention_images_dealt_to_the_xcds(device, t, causal, batch, width):
     assert torch.equal(dealt, plain)
     ref = _attention_ref(qkv_bf, batch, t, width, causal)
     assert float((dealt.float().cpu() - ref).abs().max()) < 3e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width", [768, 1024])
+def test_layernorm_24bit_rows(device, width):
+    """The LayerNorm forms on 24-bit-float rows (csrc/common.h f24_t: a row = W bf16 upper halves + W third bytes; model option
+    residual_stream_24bit): the packing helpers round-trip (to nearest on 24 bits, relative error <= 2^-16), ln_2 form LN(x + d1)
+    leaves x untouched, ln_1 form writes x += d1 + d2 back as the 24-bit rounding of the fp32 sum, outputs against torch's fp32
+    LayerNorm of the exactly unpacked rows."""
+    rows = 301
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(rows, width, generator=g) * 3
+    x[0, :4] = torch.tensor([0.0, -0.0, 1e-30, -123456.789])
+    x24 = engine.pack_f24_rows(x)
+    xq = engine.unpack_f24_rows(x24, width)
+    assert x24.shape == (rows, 3 * width) and x24.dtype == torch.uint8
+    assert float(((xq - x).abs() / x.abs().clamp_min(1e-20)).max()) <= 2.0 ** -16 + 1e-9 and torch.equal(engine.pack_f24_rows(xq), x24)
+    d1 = (torch.randn(rows, width, generator=g) * 0.5).to(torch.bfloat16)
+    d2 = (torch.randn(rows, width, generator=g) * 0.5).to(torch.bfloat16)
+    gamma, beta = 1 + 0.1 * torch.randn(width, generator=g), 0.1 * torch.randn(width, generator=g)
+    gd, bd = gamma.to(device), beta.to(device)
+    xd = x24.clone().to(device)
+
+    def close(y, ref):                                    # bf16 output: 2^-8 relative (the outlier row normalises to |y| ~ 30) + 2e-2 absolute
+        return bool(((y.float().cpu() - ref).abs() <= 2e-2 + 2.0 ** -8 * ref.abs()).all())
+
+    y0 = engine.op_layernorm_rows_f24(xd, width, None, gd, bd, writeback=False)
+    assert close(y0, torch.nn.functional.layer_norm(xq, (width,), gamma, beta, 1e-5))
+    y2 = engine.op_layernorm_rows_f24(xd, width, d1.to(device), gd, bd, writeback=False)
+    torch.cuda.synchronize()
+    assert torch.equal(xd.cpu(), x24)                                                 # untouched
+    assert close(y2, torch.nn.functional.layer_norm(xq + d1.float(), (width,), gamma, beta, 1e-5))
+    y1 = engine.op_layernorm_rows_f24(xd, width, d1.to(device), gd, bd, delta2=d2.to(device))
+    torch.cuda.synchronize()
+    xs = (xq + d1.float()) + d2.float()
+    assert torch.equal(xd.cpu(), engine.pack_f24_rows(xs))                            # the fp32 sum, rounded once to 24 bits
+    assert close(y1, torch.nn.functional.layer_norm(xs, (width,), gamma, beta, 1e-5))
