@@ -163,3 +163,11 @@ def test_host_e4m3_conversion_matches_torch():
     out2 = np.empty(4, dtype=np.uint8)
     assert lib.kemr_op_e4m3_host(C.c_void_p(big.data_ptr()), C.c_void_p(out2.ctypes.data), 4) == 0
     assert out2.tolist() == [0x7e, 0x7e, 0x7e, 0xfe]
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check (`__graft_entry__.build()`): compiles (or finds up to date) the library, loads it and checks the ABI
+    version against the binding table -- it must not lag behind a version bump."""
+    import importlib
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
