@@ -145,6 +145,11 @@ def tower_gemm_flops(width, layers, rows, items, pooled):
 
 
 def main():
+    if os.environ.get("KEMR_DEBUG_SET"):               # A/B runs only (tools/ab_env.sh): "key=value,key=value" for kemr_debug_set
+        from knowledge_enhanced_multimodal_retrieval_amd import debug
+        for kv in os.environ["KEMR_DEBUG_SET"].split(","):
+            k, v = kv.split("=")
+            debug.set(k.strip(), int(v))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="timed steps; 0 = the whole gallery shard, ceil(43000 / gpus / batch)")
