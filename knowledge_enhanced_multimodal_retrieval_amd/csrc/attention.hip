@@ -696,7 +696,8 @@ __global__ __launch_bounds__(512, 4) void attention_w8_kernel(const bf16_t* __re
 // sum) AND the staging hidden -- each alone was tried and bought nothing or lost (attention32, the persistent kernel, and, on the
 // 16-query kernel: the exponentials of block u + 1 pinned between the PV MFMAs of block u with sched_group_barrier: 152 us
 // against 150, bit-identical; the next round's rows touched ahead into L2 by 4-byte LDS-DMA: staging 8.7 k -> 6.7 k ticks but
-// 164 us).  Kept behind attn_v = 3 with its tests.
+// 164 us; every K load issued ahead of every V load, K written and the first tile's scores and softmax run while V is still on its
+// way, V written in front of that tile's PV phase: bit-identical, 152.3 against 151.2 us).  Kept behind attn_v = 3 with its tests.
 #define KEMR_ATTN_GLDS(VOFF, SBASE, LDSADDR) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" \
                                                           :: "v"(VOFF), "s"(SBASE), "s"(LDSADDR) : "memory")
 template <int NW>                                       // waves per workgroup: 8 (two tiles each) or 16 (one tile each, <= 128 VGPRs)
