@@ -26,7 +26,8 @@ extern "C" {
  *   "gemm_kl"       K loop of the persistent GEMM: 0 = eight 256-cycle barrier intervals per K-tile (default), 1 = four of 512
  *   "attn_v"        attention kernel at T = 257: 0 = the 16-query-tile kernel, 4 waves (default), 1 = 32-query tiles on
  *                   v_mfma_f32_32x32x16_bf16, 2 = eight waves per workgroup with the keys in two halves (online softmax),
- *                   3 = as 2, one persistent workgroup per CU, the next head's K / V by LDS-DMA while this one is computed
+ *                   3 = as 2, one persistent workgroup per CU, the next head's K / V by LDS-DMA while this one is computed,
+ *                   4 = two query tiles per pass sharing the K / V fragments (half the LDS bytes per tile)
  *   "attn_xcd"      attention: 1 = XCD x computes the images = x (mod 8), the heads of an image next to each other in time
  *                   (default), 0 = grid order
  *   "attn_waves"    waves per workgroup at T = 257: 0 = default (4 for attn_v 0, 16 for attn_v 3), 6 (attn_v 0), 8 (attn_v 3);

@@ -606,7 +606,7 @@ const DebugKnob* debug_knobs(int* n) {
         {"gemm_order", &g_gemm_order, 0, 8},          // gemm256u tile order (0 = N fastest, else log2(column-group width) + 1)
         {"gemm_conc", &g_gemm_conc, 0, 2},            // both wave halves' epilogues in one barrier interval: 0 never, 1 always, 2 = QuickGELU only
         {"gemm_kl", &g_gemm_kl, 0, 1},                // 0 = eight 256-cycle barrier intervals per K-tile (default), 1 = four of 512 (round-3 experiment)
-        {"attn_v", &g_attn_v, 0, 3},                  // 0 = the 16-query-tile kernel (default), 1 = 32-query tiles on the 32x32x16 MFMA at T = 257 (round-3 experiment)
+        {"attn_v", &g_attn_v, 0, 4},                  // 0 = the 16-query-tile kernel (default), 1 = 32-query tiles on the 32x32x16 MFMA at T = 257 (round-3 experiment)
         {"attn_xcd", &g_attn_xcd, 0, 1},              // attention: images dealt to the XCDs
         {"attn_waves", &g_attn_waves, 0, 8},          // waves per attention workgroup at T = 257 (0 = default)
         {"sim_lists", sim_lists_knob(), 0, 3},        // 0 = never the candidate-list route, 1 = where it pays, 2 = wherever it fits + the fallback forced, 3 = wherever it fits

@@ -664,6 +664,178 @@ __global__ __launch_bounds__(512, 4) void attention_w8_kernel(const bf16_t* __re
     if (wid == 0 && lrow == 0) attn_w8_merge<8>(sP, out, b, h, width, lq);
 }
 
+// ---- T = 257, two query tiles per pass sharing the K / V fragments (round 3 experiment, attn_v = 4) -------------------------------------
+// The 16-query kernel is bound per CU by LDS bytes (71.7 KB per tile) and by VALU + MFMA issue, not by its staging (notes at the persistent
+// kernel below).  Here a wave computes TWO query tiles at once through the key halves of the online softmax: every K fragment and every
+// transposed V fragment it reads from LDS feeds two MFMAs instead of one (half the LDS bytes per tile), and the two tiles are independent
+// instruction streams that hipcc may overlap.  Four waves per workgroup, two workgroups per CU as the 16-query kernel; 16 full tiles
+// = 8 pairs, two per wave; the lone 257th query split over the four waves by 32-key block and merged through LDS as in the eight-wave kernel.
+// Measured: 220 VGPRs, no scratch, correct at once (the tests of the other kernels), 153.5 - 155.3 us against 150.2 - 152.6 for the 16-query
+// kernel on the same box: half the LDS bytes per tile buy nothing either.  With the eight-wave kernel (twice the waves), the persistent
+// kernel (no staging phase), the pinned MFMA / exponential interleaving and this one, four different shapes of the same work land within
+// 5 % of each other, which says the launch is bound by what they share: per tile 72 quarter-rate exponentials and ~170 other VALU
+// instructions per lane, 72 MFMAs, and the q | k | v rows crossing the chip once.  Kept behind attn_v = 4 with its tests.
+template <int NT, bool FIRST, bool MASK>
+__device__ __forceinline__ void attn_range2(const bf16x8 (&qa)[2], const bf16x8 (&qb)[2], int t_lo, int T, const char* sK, const char* sV,
+                                            int lrow, int lq, AttnAcc& a, AttnAcc& b) {
+    constexpr float LOG2E = 1.4426950408889634f;
+    f32x4 sa[NT], sb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const char* kr = sK + ((t_lo + t) * 16 + lrow) * 128;
+        const bf16x8 k0 = *(const bf16x8*)(kr + ((lq ^ (lrow >> 1)) << 4));
+        const bf16x8 k1 = *(const bf16x8*)(kr + (((4 + lq) ^ (lrow >> 1)) << 4));
+        sa[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qa[0], sa[t], 0, 0, 0);
+        sb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qb[0], sb[t], 0, 0, 0);
+        sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qa[1], sa[t], 0, 0, 0);
+        sb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qb[1], sb[t], 0, 0, 0);
+    }
+    auto soft = [&](f32x4 (&s)[NT], AttnAcc& acc) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (MASK) s[t][r] = ((t_lo + t) * 16 + lq * 4 + r) < T ? s[t][r] : -INFINITY;
+                mx = fmaxf(mx, s[t][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = FIRST ? mx : fmaxf(acc.m, mx);
+        const float mxl = m_new * LOG2E;
+        f32x2_t sum2 = {0.f, 0.f};
+        const f32x2_t l2 = {LOG2E, LOG2E}, nm = {-mxl, -mxl};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x2_t x = f32x2_t{s[t][0], s[t][1]} * l2 + nm, y = f32x2_t{s[t][2], s[t][3]} * l2 + nm;
+            x.x = __builtin_amdgcn_exp2f(x.x); x.y = __builtin_amdgcn_exp2f(x.y);
+            y.x = __builtin_amdgcn_exp2f(y.x); y.y = __builtin_amdgcn_exp2f(y.y);
+            s[t][0] = x.x; s[t][1] = x.y; s[t][2] = y.x; s[t][3] = y.y;
+            sum2 += x;
+            sum2 += y;
+        }
+        if constexpr (FIRST) {
+            acc.l = sum2.x + sum2.y;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc.o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            const float alpha = __builtin_amdgcn_exp2f((acc.m - m_new) * LOG2E);
+            acc.l = acc.l * alpha + (sum2.x + sum2.y);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc.o[dt] *= alpha;
+        }
+        acc.m = m_new;
+    };
+    soft(sa, a);
+    soft(sb, b);
+#pragma unroll
+    for (int u = 0; u < NT / 2; ++u) {
+        const int ra = (t_lo + 2 * u) * 16 + lq * 4 + (lrow >> 2), rb = ra + 16;
+        union { bf16x8 v; uint32_t w[4]; } pa, pb;
+        pa.w[0] = pack_bf16x2(sa[2 * u][0], sa[2 * u][1]);
+        pa.w[1] = pack_bf16x2(sa[2 * u][2], sa[2 * u][3]);
+        pa.w[2] = pack_bf16x2(sa[2 * u + 1][0], sa[2 * u + 1][1]);
+        pa.w[3] = pack_bf16x2(sa[2 * u + 1][2], sa[2 * u + 1][3]);
+        pb.w[0] = pack_bf16x2(sb[2 * u][0], sb[2 * u][1]);
+        pb.w[1] = pack_bf16x2(sb[2 * u][2], sb[2 * u][3]);
+        pb.w[2] = pack_bf16x2(sb[2 * u + 1][0], sb[2 * u + 1][1]);
+        pb.w[3] = pack_bf16x2(sb[2 * u + 1][2], sb[2 * u + 1][3]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int c = dt * 2 + ((lrow & 3) >> 1);
+            const bf16x4 va = lds_read_tr16(sV + ra * 128 + ((c ^ (((ra >> 1) & 3) << 1)) << 4) + (lrow & 1) * 8);
+            const bf16x4 vb = lds_read_tr16(sV + rb * 128 + ((c ^ (((rb >> 1) & 3) << 1)) << 4) + (lrow & 1) * 8);
+            bf16x8 vf;
+            vf[0] = va[0]; vf[1] = va[1]; vf[2] = va[2]; vf[3] = va[3];
+            vf[4] = vb[0]; vf[5] = vb[1]; vf[6] = vb[2]; vf[7] = vb[3];
+            a.o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pa.v, a.o[dt], 0, 0, 0);
+            b.o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb.v, b.o[dt], 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attention_s2_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int width, int xbatch) {
+    constexpr int T = 257, TP = 288, NTH = 256, NCH = (TP * 8 + NTH - 1) / NTH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = smem + TP * 128;
+    float* sP = (float*)(smem + 2 * TP * 128);          // partials of the lone query: 4 waves x (64 o + m + l), padded to 68 floats
+    int h, b;
+    if (!attn_item(xbatch, h, b)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ld = 3 * width;
+    const bf16_t* base = qkv + (size_t)b * T * ld + h * 64;
+    const int lrow = lane & 15, lq = lane >> 4;
+    auto load_q = [&](int q0, bf16x8 (&qf)[2]) {
+        const int qc = q0 + lrow < T ? q0 + lrow : T - 1;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const bf16x8*)(base + (size_t)qc * ld + kk * 32 + lq * 8);
+    };
+    bf16x8 qa[2], qb[2];
+    load_q(wid * 32, qa);
+    load_q(wid * 32 + 16, qb);
+    {
+        uint4 kv[NCH], vv[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + i * NTH;
+            const int row = idx >> 3, c = idx & 7;
+            const int rc = row < T ? row : T - 1;
+            kv[i] = *(const uint4*)(base + (size_t)rc * ld + width + c * 8);
+            vv[i] = *(const uint4*)(base + (size_t)rc * ld + 2 * width + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + i * NTH;
+            const int row = idx >> 3, c = idx & 7;
+            if (idx < TP * 8) {
+                const unsigned keep = row < T ? 0xffffffffu : 0u;
+                uint4 a = kv[i], b2 = vv[i];
+                a.x &= keep; a.y &= keep; a.z &= keep; a.w &= keep;
+                b2.x &= keep; b2.y &= keep; b2.z &= keep; b2.w &= keep;
+                *(uint4*)(sK + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = a;
+                *(uint4*)(sV + row * 128 + ((c ^ (((row >> 1) & 3) << 1)) << 4)) = b2;
+            }
+        }
+    }
+    __syncthreads();
+    AttnAcc accA, accB;
+#pragma unroll 1
+    for (int pr = 0; pr < 2; ++pr) {                    // pairs wid and 4 + wid: tiles 2 pair, 2 pair + 1
+        const int q0 = (pr * 4 + wid) * 32;
+        bf16x8 na[2], nb[2];
+        if (pr == 0) { load_q(q0 + 128, na); load_q(q0 + 144, nb); }       // the second pair's queries, ahead
+        attn_range2<10, true, false>(qa, qb, 0, T, sK, sV, lrow, lq, accA, accB);
+        attn_range2<8, false, true>(qa, qb, 10, T, sK, sV, lrow, lq, accA, accB);
+        attn_w8_store(accA, out, b, h, q0, width, lrow, lq);
+        attn_w8_store(accB, out, b, h, q0 + 16, width, lrow, lq);
+        asm volatile("" ::: "memory");
+        if (pr == 0) { qa[0] = na[0]; qa[1] = na[1]; qb[0] = nb[0]; qb[1] = nb[1]; }
+    }
+    // the 257th query: 32-key blocks w, w + 4 (and block 8, where only key 256 is real, on wave 0)
+    bf16x8 ql[2];
+    load_q(256, ql);
+    attn_range<2, true, false>(ql, 2 * wid, T, sK, sV, lrow, lq, accA);
+    attn_range<2, false, false>(ql, 2 * (wid + 4), T, sK, sV, lrow, lq, accA);
+    if (wid == 0) attn_range<2, false, true>(ql, 16, T, sK, sV, lrow, lq, accA);
+    {
+        float l = accA.l;
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        if (lrow == 0) {
+            float* dstp = sP + wid * 68;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *(f32x4*)(dstp + dt * 16 + lq * 4) = accA.o[dt];
+            if (lq == 0) { dstp[64] = accA.m; dstp[65] = l; }
+        }
+    }
+    __syncthreads();
+    if (wid == 0 && lrow == 0) attn_w8_merge<4>(sP, out, b, h, width, lq);
+}
+
 // ---- T = 257, persistent, K / V of the next head by LDS-DMA while this one is computed (round 3, attn_v = 3) ---------------------------
 // One workgroup per CU walks a list of (image, head) items with two K / V buffers in LDS (2 x 72 KiB): the rows of item n + 1 are moved
 // by global_load_lds_dwordx4 (no registers, nothing for hipcc to schedule or to copy: with the prefetch held in 40 VGPRs it sank the
@@ -790,7 +962,8 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void attention_pd_kernel
 // VGPRs with 28 bytes of scratch and takes 199-208 us against 178-184 on the same device.  A second tile in flight needs the
 // schedule written by hand, as the GEMM's is.)
 int g_attn_v = 0;          // tools, T = 257: 0 = the 16-query-tile kernel (default), 1 = 32-query tiles on the 32x32x16 MFMA, 2 = eight waves /
-                           // keys in two halves, 3 = 2 as a persistent workgroup per CU with the next head's K / V by LDS-DMA
+                           // keys in two halves, 3 = 2 as a persistent workgroup per CU with the next head's K / V by LDS-DMA, 4 = two query
+                           // tiles per pass sharing the K / V fragments
 
 int g_attn_xcd = 1;        // 1 = the images dealt to the XCDs (attn_item above; default), 0 = grid order (tools)
 int g_attn_waves = 0;      // tools: 0 = the default choice below, else waves per workgroup for the 257-token shape (4 or 6)
@@ -820,7 +993,11 @@ static int launch_nt(const bf16_t* qkv, bf16_t* out, int batch, int t, int width
         if (NT32 == 3 && t == 77 && !row_start) { kern = attention_kernel<NT32, true, NT32 == 3 ? 77 : 0, NT32 == 3 ? 5 : 4>; threads = 320; }
         else kern = attention_kernel<NT32, true, 0>;
     } else if (NT32 == 9 && t == 257 && g_attn_v >= 2) {
-        if (g_attn_v == 3) {
+        if (g_attn_v == 4) {
+            constexpr int smem2 = 2 * 288 * 128 + 4 * 68 * 4;
+            KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)attention_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem2));
+            hipLaunchKernelGGL(attention_s2_kernel, xgrid, dim3(256), smem2, stream, qkv, out, width, xbatch);
+        } else if (g_attn_v == 3) {
             constexpr int smemp = 4 * 288 * 128 + 9 * 68 * 4;
             int num_cu = 0;
             if (int rc = attention_num_cu(&num_cu)) return rc;

@@ -434,7 +434,7 @@ def test_attention_257_both_kernels_and_exact_structure(device, batch, width):
     qkv_bf = qkv.to(torch.bfloat16)
     ref = _attention_ref(qkv_bf, batch, t, width, False)
     outs = {}
-    for v in (0, 1, 2, 3):
+    for v in (0, 1, 2, 3, 4):
         with debug.override(attn_v=v):
             outs[v] = engine.op_attention(qkv_bf.to(device), batch, t, width, False).float().cpu()
         assert float((outs[v] - ref).abs().max()) < 3e-2 and float((outs[v] - ref).abs().mean()) < 3e-3, v
@@ -464,7 +464,7 @@ def test_attention_257_both_kernels_and_exact_structure(device, batch, width):
     want = torch.empty(batch * t, width)
     for b in range(batch):
         want[b * t:(b + 1) * t] = vals[b * t:(b + 1) * t][perm]
-    for v in (0, 1, 2, 3):
+    for v in (0, 1, 2, 3, 4):
         with debug.override(attn_v=v):
             got = engine.op_attention(xb.to(device), batch, t, width, False).float().cpu()
         assert float((got - want).abs().max()) < 1e-6, (v, float((got - want).abs().max()))
@@ -487,7 +487,7 @@ def test_attention_257_online_softmax_rescale_is_exercised(device, spike_key):
     qkv_bf = qkv.to(torch.bfloat16)
     ref = _attention_ref(qkv_bf, batch, t, width, False)
     outs = {}
-    for v in (0, 2, 3):
+    for v in (0, 2, 3, 4):
         with debug.override(attn_v=v):
             outs[v] = engine.op_attention(qkv_bf.to(device), batch, t, width, False).float().cpu()
         assert torch.isfinite(outs[v]).all()
