@@ -279,7 +279,10 @@ int kemr_preprocess_u8(const unsigned char* img_dev, int height, int width, int 
                        void* workspace_dev, size_t workspace_bytes, void* stream);
 /* A whole loader batch in ONE launch pair: `batch` uint8 HWC images of any sizes packed back to back in packed_dev
  * (image b starts at byte offsets[b] and has heights[b] x widths[b] pixels; the three arrays are HOST arrays) ->
- * out_dev fp32 [batch, 3, n_px, n_px].  Same arithmetic, bit for bit, as kemr_preprocess_u8 per image. */
+ * out_dev fp32 [batch, 3, n_px, n_px].  Same arithmetic, bit for bit, as kemr_preprocess_u8 per image.
+ * An item with heights[b] == widths[b] == 0 is one the caller could not decode: it has no bytes in packed_dev and its
+ * output is 0.0f everywhere, i.e. zeros AFTER normalisation -- the tensor the reference's dataset substitutes
+ * (src/clip/datasets/clip_dataset.py:120-125, torch.zeros(3, 224, 224)).  Any other non-positive size is KEMR_ERR_INVALID. */
 size_t kemr_preprocess_batch_workspace_bytes(const int32_t* heights, const int32_t* widths, int batch, int n_px);
 int kemr_preprocess_u8_batch(const unsigned char* packed_dev, const int64_t* offsets, const int32_t* heights,
                              const int32_t* widths, int batch, int n_px, float* out_dev, void* workspace_dev,

@@ -15,27 +15,34 @@ extern "C" {
 #endif
 
 /* One key per switch; a call touches that switch only.
- *   "gemm_variant"  0 = automatic (default), 1 = 128x128x64 / 4 waves, 2 / 3 = 256x256x64 / 8 waves in lockstep / staggered,
+ * PRODUCT library (the default build): a switch only ROUTES between kernels the product needs anyway.  The experiment kernels of
+ * rounds 1-3 (earlier GEMM generations, the staggered 256x256 GEMM, the long-interval K loop, the stamped / store-dropping GEMM
+ * instantiations, the attention variants) are compiled only by `python -m knowledge_enhanced_multimodal_retrieval_amd.build
+ * --ab-variants`; without them every value marked [A/B] below is refused with KEMR_ERR_INVALID.  "ab_variants" (read-only) says
+ * which library this is.
+ *   "gemm_variant"  0 = automatic (default), 1 = 128x128x64 / 4 waves, 2 = 256x256x64 / 8 waves in lockstep,
  *                   7 = persistent 8 waves with one K-tile pipeline across tiles (the automatic choice from 128 tiles up),
- *                   8 = skinny-M split-K (automatic up to 512 rows); 4, 5, 6, 9 = earlier persistent generations, only in a
- *                   library built with `build.py --ab-variants`
- *   "gemm_flags"    timing experiments of the persistent GEMM's diagnostic instantiation: 1 = drop the C stores, 4 = plain
+ *                   8 = skinny-M split-K (automatic up to 512 rows); [A/B] 3 = 256x256x64 staggered, 4, 5, 6, 9 = earlier
+ *                   persistent generations
+ *   "gemm_flags"    [A/B] timing experiments of the persistent GEMM's diagnostic instantiation: 1 = drop the C stores, 4 = plain
  *                   instead of non-temporal stores, 64 (+ 32) = cycle stamps per barrier interval, 128 = whole-kernel clock
  *   "gemm_order"    tile order of the persistent GEMM: 0 = N fastest, else log2(column-group width) + 1 (default 3)
  *   "gemm_conc"     both wave halves' epilogues in one barrier interval: 0 never, 1 always, 2 = QuickGELU epilogue only (default)
- *   "gemm_kl"       K loop of the persistent GEMM: 0 = eight 256-cycle barrier intervals per K-tile (default), 1 = four of 512
- *   "attn_v"        attention kernel at T = 257: 0 = the 16-query-tile kernel, 4 waves (default), 1 = 32-query tiles on
- *                   v_mfma_f32_32x32x16_bf16, 2 = eight waves per workgroup with the keys in two halves (online softmax),
- *                   3 = as 2, one persistent workgroup per CU, the next head's K / V by LDS-DMA while this one is computed,
- *                   4 = two query tiles per pass sharing the K / V fragments (half the LDS bytes per tile)
+ *   "gemm_kl"       K loop of the persistent GEMM: 0 = eight 256-cycle barrier intervals per K-tile (the product loop),
+ *                   [A/B] 1 = four of 512
+ *   "attn_v"        attention kernel at T = 257: 0 = the product kernel (16-query tiles, 4 waves); [A/B, csrc/attention_ab.hip]
+ *                   1 = 32-query tiles on v_mfma_f32_32x32x16_bf16, 2 = eight waves per workgroup with the keys in two halves
+ *                   (online softmax), 3 = as 2, one persistent workgroup per CU, the next head's K / V by LDS-DMA while this one
+ *                   is computed, 4 = two query tiles per pass sharing the K / V fragments (half the LDS bytes per tile)
  *   "attn_xcd"      attention: 1 = XCD x computes the images = x (mod 8), the heads of an image next to each other in time
  *                   (default), 0 = grid order
- *   "attn_waves"    waves per workgroup at T = 257: 0 = default (4 for attn_v 0, 16 for attn_v 3), 6 (attn_v 0), 8 (attn_v 3);
+ *   "attn_waves"    [A/B] waves per workgroup at T = 257: 0 = default (4 for attn_v 0, 16 for attn_v 3), 6 (attn_v 0), 8 (attn_v 3);
  *                   2 (attn_v 0) = the build with s_memtime stamps, which writes 8 counters per wave BEHIND the output
  *                   (tools/prof_attention.py allocates the room; nothing else may select it)
  *   "sim_lists"     kemr_sim_topk: 0 = never the candidate-list route (nor the fast rank pass for bonus lists), 1 = where it pays
  *                   (default: from 2 048 gallery rows, 256 queries and 1.2e10 multiply-adds up), 3 = wherever it fits, 2 = as 3 and
- *                   the exact fallback forced to run after the lists */
+ *                   the exact fallback forced to run after the lists
+ *   "ab_variants"   read-only: 1 = the library holds the [A/B] kernels */
 int kemr_debug_set(const char* key, int value);
 int kemr_debug_get(const char* key, int* value);
 

@@ -19,9 +19,11 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "libkemr.so")
 SOURCES = ["api.hip", "gemm.hip", "gemm256.hip", "gemm256u.hip", "gemm_skinny.hip", "layernorm.hip", "attention.hip", "embed.hip", "sim.hip", "rank.hip", "preprocess.hip"]
-# Earlier persistent-GEMM generations kept for A/B timing from tools/ only (variants 4, 5, 6, 9 of kemr_set_gemm_variant): built
-# into the library only with `python -m ...build --ab-variants` (or KEMR_BUILD_AB=1), never into the product library.
-AB_SOURCES = ["gemm256p.hip", "gemm256q.hip", "gemm256w.hip", "gemm256r.hip"]
+# Experiment kernels kept for A/B timing from tools/ only -- earlier persistent-GEMM generations (gemm_variant 4, 5, 6, 9), the
+# attention variants of round 3 (attn_v 1..4), and, inside the product sources behind -DKEMR_AB_VARIANTS, the staggered 256x256
+# GEMM, the long-interval K loop, the stamped instantiations: built only with `python -m ...build --ab-variants` (or
+# KEMR_BUILD_AB=1), never into the product library, whose kemr_debug_set refuses the values that would select them.
+AB_SOURCES = ["gemm256p.hip", "gemm256q.hip", "gemm256w.hip", "gemm256r.hip", "attention_ab.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "kemr.h")]
 ARCH = "gfx950"
 

@@ -82,6 +82,7 @@ class CLIP(nn.Module):
         self.text_projection = nn.Parameter(torch.empty(arch.t_width, arch.embed_dim))
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
         self._engine: Optional[ClipEngine] = None
+        self._gpu_pre = None
         self._packed_fp = None
         self._dirty = True
         self.initialize_parameters()
@@ -145,13 +146,14 @@ class CLIP(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = None if k in ("_engine", "_packed_fp") else copy.deepcopy(v, memo)
+            new.__dict__[k] = None if k in ("_engine", "_packed_fp", "_gpu_pre") else copy.deepcopy(v, memo)
         new._dirty = True
         return new
 
     def __getstate__(self):
         state = dict(self.__dict__)
         state["_engine"], state["_packed_fp"], state["_dirty"] = None, None, True
+        state["_gpu_pre"] = None
         return state
 
     def engine(self) -> ClipEngine:
@@ -172,7 +174,16 @@ class CLIP(nn.Module):
     # ------------------------------------------------------------------ the duck-typed API
     @torch.no_grad()
     def encode_image(self, image: torch.Tensor, normalize: bool = False) -> torch.Tensor:
-        return self.engine().encode_image(image.to(self.visual.proj.device), normalize=normalize)
+        """``image``: float ``[B, 3, S, S]`` normalised pixels as upstream, or the :class:`preprocess.PackedRaw` batch a loader over
+        ``CLIPEvalDatasetHF(split, preprocess)`` yields when the transform is deferred to the GPU -- so the reference's own loop
+        (``images.to(device)`` -> ``model.encode_image(images)``, evaluator.py:118-121) runs unchanged on either."""
+        from .preprocess import ClipPreprocessGPU, PackedRaw
+        dev = self.visual.proj.device
+        if isinstance(image, PackedRaw):
+            if getattr(self, "_gpu_pre", None) is None or self._gpu_pre.device != dev:
+                self._gpu_pre = ClipPreprocessGPU(self.visual.input_resolution, dev)
+            image = self._gpu_pre.batch(image)
+        return self.engine().encode_image(image.to(dev), normalize=normalize)
 
     accepts_text_lengths = True        # encode_text(..., lens=host int tensor): evaluators.encode_dataset passes the tokenizer-side lengths
 

@@ -597,19 +597,27 @@ extern "C" int kemr_model_get_option(const kemr_model* m, const char* key, int* 
 // ------------------------------------------------------------------------------------------------ include/kemr_debug.h
 // Process-wide experiment switches of tools/ and tests/ (not thread-safe, not part of the product ABI): one key per knob.
 namespace {
-struct DebugKnob { const char* key; int* var; int lo, hi; };
+#ifdef KEMR_AB_VARIANTS
+int g_ab_variants = 1;
+#else
+int g_ab_variants = 0;
+#endif
+// `product`: bit v set = value v selects a kernel the PRODUCT library holds (a routing choice between kernels it needs anyway);
+// every other value names an experiment kernel that exists only in a `build.py --ab-variants` library and is refused without it.
+struct DebugKnob { const char* key; int* var; int lo, hi; unsigned product; };
 int* sim_lists_knob();
 const DebugKnob* debug_knobs(int* n) {
     static const DebugKnob knobs[] = {
-        {"gemm_variant", &g_gemm_variant, 0, 9},      // 0 auto, 1 = 128x128, 2 / 3 = 256x256 lockstep / staggered, 4-6, 9 = A/B generations (build.py --ab-variants), 7 = persistent, 8 = skinny
-        {"gemm_flags", &g_gemm_dbg, 0, 255},          // timing-experiment flags of the DBG instantiation (1 drop stores, 4 plain stores, 32 / 64 / 128 stamps)
-        {"gemm_order", &g_gemm_order, 0, 8},          // gemm256u tile order (0 = N fastest, else log2(column-group width) + 1)
-        {"gemm_conc", &g_gemm_conc, 0, 2},            // both wave halves' epilogues in one barrier interval: 0 never, 1 always, 2 = QuickGELU only
-        {"gemm_kl", &g_gemm_kl, 0, 1},                // 0 = eight 256-cycle barrier intervals per K-tile (default), 1 = four of 512 (round-3 experiment)
-        {"attn_v", &g_attn_v, 0, 4},                  // 0 = the 16-query-tile kernel (default), 1 = 32-query tiles on the 32x32x16 MFMA at T = 257 (round-3 experiment)
-        {"attn_xcd", &g_attn_xcd, 0, 1},              // attention: images dealt to the XCDs
-        {"attn_waves", &g_attn_waves, 0, 8},          // waves per attention workgroup at T = 257 (0 = default)
-        {"sim_lists", sim_lists_knob(), 0, 3},        // 0 = never the candidate-list route, 1 = where it pays, 2 = wherever it fits + the fallback forced, 3 = wherever it fits
+        {"gemm_variant", &g_gemm_variant, 0, 9, 1u << 0 | 1u << 1 | 1u << 2 | 1u << 7 | 1u << 8},   // 0 auto, 1 = 128x128, 2 = 256x256, 7 = persistent, 8 = skinny (all product kernels, forced); 3 = staggered 256x256, 4-6, 9 = earlier generations: A/B builds
+        {"gemm_flags", &g_gemm_dbg, 0, 255, 1u << 0},  // timing-experiment flags of the DBG instantiation (1 drop stores, 4 plain stores, 32 / 64 / 128 stamps): A/B builds
+        {"gemm_order", &g_gemm_order, 0, 8, ~0u},     // gemm256u tile order (0 = N fastest, else log2(column-group width) + 1)
+        {"gemm_conc", &g_gemm_conc, 0, 2, ~0u},       // both wave halves' epilogues in one barrier interval: 0 never, 1 always, 2 = QuickGELU only
+        {"gemm_kl", &g_gemm_kl, 0, 1, 1u << 0},       // 0 = eight 256-cycle barrier intervals per K-tile (the product loop), 1 = four of 512 (round-3 experiment): A/B builds
+        {"attn_v", &g_attn_v, 0, 4, 1u << 0},         // 0 = the product kernel, 1..4 = attention_ab.hip: A/B builds
+        {"attn_xcd", &g_attn_xcd, 0, 1, ~0u},         // attention: images dealt to the XCDs
+        {"attn_waves", &g_attn_waves, 0, 8, 1u << 0}, // waves per attention workgroup at T = 257 (0 = default; others: A/B builds)
+        {"sim_lists", sim_lists_knob(), 0, 3, ~0u},   // 0 = never the candidate-list route, 1 = where it pays, 2 = wherever it fits + the fallback forced, 3 = wherever it fits
+        {"ab_variants", &g_ab_variants, -1, -2, 0},   // read-only: 1 = this library was built with the A/B experiment kernels
     };
     *n = (int)(sizeof(knobs) / sizeof(knobs[0]));
     return knobs;
@@ -623,7 +631,10 @@ extern "C" int kemr_debug_set(const char* key, int value) {
     const DebugKnob* k = debug_knobs(&n);
     for (int i = 0; i < n; ++i)
         if (!strcmp(k[i].key, key)) {
+            if (k[i].lo > k[i].hi) KEMR_FAIL(KEMR_ERR_INVALID, "debug_set(%s): read-only", key);
             if (value < k[i].lo || value > k[i].hi) KEMR_FAIL(KEMR_ERR_INVALID, "debug_set(%s): %d not in %d..%d", key, value, k[i].lo, k[i].hi);
+            if (!g_ab_variants && !(value < 32 && ((k[i].product >> value) & 1u)) && k[i].product != ~0u)
+                KEMR_FAIL(KEMR_ERR_INVALID, "debug_set(%s): %d selects an A/B experiment kernel that is not in this library (build.py --ab-variants)", key, value);
             *k[i].var = value;
             return KEMR_OK;
         }

@@ -265,720 +265,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
     }
 }
 
-// ---- T = 257 (ViT-L/14 and ViT-B/16 vision towers): 32-query tiles on v_mfma_f32_32x32x16_bf16 (round 3) ---------------------------
-// Round 2's PMC pass of the 16-query kernel above put a wave at one third issuing, one third parked at s_waitcnt and one third
-// issue-stalled, MFMA pipe 20 % busy: per 16 queries it issues 72 MFMAs, 36 + 72 LDS reads and ~1 100 cycles of softmax VALU, with
-// every phase waiting on the one before.  A 32 x 32 tile halves the MFMA and LDS-read instructions per query (one K / V fragment
-// serves 32 queries), an MFMA holds the issue port for 8 of its 32 cycles instead of 8 of 16, and 257 queries are 8 full tiles --
-// two per wave, balanced -- plus ONE query (the 16-query kernel: 17 tiles as 5 / 4 / 4 / 4).
-//   S^T block (32 keys x 32 queries) = K_blk . Q^T: A = K rows (ds_read_b128: lane (key l & 31, half l >> 5) holds d = 16 ks + 8 half
-//   .. + 7), B = Q rows straight from HBM in the same shape; a lane ends with 16 keys of ONE query per block (C layout: key =
-//   (reg & 3) + 8 (reg >> 2) + 4 half), so row max / sum are the in-lane reduction and one exchange with lane ^ 32.
-//   O^T (64 x 32) += V^T . P^T per 16-key step: the score registers 8 st .. 8 st + 7, packed to bf16, ARE the B fragment (k slot
-//   8 half + j <-> key 16 st + 8 (j >> 2) + 4 half + (j & 3)); the A fragment takes the same keys from the row-major V image with two
-//   ds_read_b64_tr_b16 (rows 16 st + 4 half + 0..3 and + 8).
-// LDS images: K as above (chunk ^= (row >> 1) & 7: conflict-free for both MFMA shapes); V rows of 128 B with the 32-byte chunk index
-// ^= ((row >> 1) & 1) << 1 | ((row >> 2) & 1), which makes the half-wave patterns of BOTH shapes conflict-free (this one reads 4 rows
-// x 64 B per half wave, the 16 x 16 one 8 rows x 32 B).
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-__device__ __forceinline__ int v_swz32(int row) { return (((row >> 1) & 1) << 1) | ((row >> 2) & 1); }
-
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attention32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int width) {
-    constexpr int T = 257, NKB = 9, TP = NKB * 32, NTH = NW * 64, NCH = (TP * 8 + NTH - 1) / NTH, NQT = (T + 31) / 32;
-    constexpr float LOG2E = 1.4426950408889634f;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;
-    char* sV = smem + TP * 128;
-    int h, b;
-    if (!attn_item(0, h, b)) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ld = 3 * width;
-    const bf16_t* base = qkv + (size_t)b * T * ld + h * 64;
-    const int r32 = lane & 31, hh = lane >> 5;
-
-    // first query tile of this wave: its loads go out before the K / V staging so that their latency overlaps it
-    bf16x8 qn[4];
-    {
-        const int q0 = wid * 32 + r32;
-        const int qc = q0 < T ? q0 : T - 1;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qn[ks] = *(const bf16x8*)(base + (size_t)qc * ld + ks * 16 + hh * 8);
-    }
-    {
-        uint4 kv[NCH], vv[NCH];
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int idx = tid + i * NTH;
-            const int row = idx >> 3, c = idx & 7;
-            const int rc = row < T ? row : T - 1;
-            kv[i] = *(const uint4*)(base + (size_t)rc * ld + width + c * 8);
-            vv[i] = *(const uint4*)(base + (size_t)rc * ld + 2 * width + c * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int idx = tid + i * NTH;
-            const int row = idx >> 3, c = idx & 7;
-            if (idx < TP * 8) {
-                const unsigned keep = row < T ? 0xffffffffu : 0u;
-                uint4 a = kv[i], b2 = vv[i];
-                a.x &= keep; a.y &= keep; a.z &= keep; a.w &= keep;
-                b2.x &= keep; b2.y &= keep; b2.z &= keep; b2.w &= keep;
-                *(uint4*)(sK + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = a;
-                *(uint4*)(sV + row * 128 + ((((c >> 1) ^ v_swz32(row)) << 5) | ((c & 1) << 4))) = b2;
-            }
-        }
-    }
-    __syncthreads();
-
-    // per-lane LDS offsets that do not depend on the block: K row r32, V rows 4 hh + (i >> 2) and columns of the lane's 16-lane group
-    const int kswz = (r32 >> 1) & 7;
-    const int vi = lane & 15, vg = (lane >> 4) & 1;
-    for (int qt = wid; qt < NQT; qt += NW) {           // wave-uniform trip count: EXEC stays full for the tr reads
-        const int q = qt * 32 + r32;
-        bf16x8 qf[4] = {qn[0], qn[1], qn[2], qn[3]};
-        if (qt + NW < NQT) {
-            const int q2 = q + NW * 32;
-            const int qc = q2 < T ? q2 : T - 1;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qn[ks] = *(const bf16x8*)(base + (size_t)qc * ld + ks * 16 + hh * 8);
-        }
-        // ---- S^T: nine blocks of 32 keys, K fragments of the next block in flight while this block's four MFMAs issue
-        f32x16 s[NKB];
-        bf16x8 kfr[2][4];
-        auto load_k = [&](int kb, bf16x8 (&dst)[4]) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                dst[ks] = *(const bf16x8*)(sK + (kb * 32 + r32) * 128 + (((ks * 2 + hh) ^ kswz) << 4));
-        };
-        load_k(0, kfr[0]);
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-            if (kb + 1 < NKB) load_k(kb + 1, kfr[(kb + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb & 1][ks], qf[ks], s[kb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // s[kb][r] = S[query r32][key kb*32 + (r & 3) + 8 (r >> 2) + 4 hh]; of the last block only key 256 exists
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (kb == NKB - 1) {
-                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    s[kb][r] = key < T ? s[kb][r] : -INFINITY;
-                }
-                mx = fmaxf(mx, s[kb][r]);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float mxl = mx * LOG2E;
-        f32x2_t sum2 = {0.f, 0.f};
-        const f32x2_t l2 = {LOG2E, LOG2E}, nm = {-mxl, -mxl};
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                f32x2_t a = f32x2_t{s[kb][r], s[kb][r + 1]} * l2 + nm;
-                a.x = __builtin_amdgcn_exp2f(a.x);
-                a.y = __builtin_amdgcn_exp2f(a.y);
-                s[kb][r] = a.x;
-                s[kb][r + 1] = a.y;
-                sum2 += a;
-            }
-        float sum = sum2.x + sum2.y;
-        sum += __shfl_xor(sum, 32);
-
-        // ---- O^T += V^T . P^T: per block two 16-key steps x two 32-row halves of d
-        f32x16 o[2];
-#pragma unroll
-        for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dh][r] = 0.f;
-        auto load_v = [&](int kb, int st, bf16x8 (&dst)[2]) {
-            const int ra = kb * 32 + 16 * st + 4 * hh + (vi >> 2), rb = ra + 8;
-#pragma unroll
-            for (int dh = 0; dh < 2; ++dh) {
-                const int c32 = dh * 2 + vg;
-                const bf16x4 va = lds_read_tr16(sV + ra * 128 + ((c32 ^ v_swz32(ra)) << 5) + (vi & 3) * 8);
-                const bf16x4 vb = lds_read_tr16(sV + rb * 128 + ((c32 ^ v_swz32(rb)) << 5) + (vi & 3) * 8);
-                dst[dh][0] = va[0]; dst[dh][1] = va[1]; dst[dh][2] = va[2]; dst[dh][3] = va[3];
-                dst[dh][4] = vb[0]; dst[dh][5] = vb[1]; dst[dh][6] = vb[2]; dst[dh][7] = vb[3];
-            }
-        };
-        constexpr int NST = 2 * NKB - 1;                // the last block's second step holds pad keys only
-        bf16x8 vfr[2][2];
-        load_v(0, 0, vfr[0]);
-#pragma unroll
-        for (int u = 0; u < NST; ++u) {
-            const int kb = u >> 1, st = u & 1;
-            if (u + 1 < NST) load_v((u + 1) >> 1, (u + 1) & 1, vfr[(u + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            union { bf16x8 v; uint32_t w[4]; } pf;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pf.w[j] = pack_bf16x2(s[kb][8 * st + 2 * j], s[kb][8 * st + 2 * j + 1]);
-#pragma unroll
-            for (int dh = 0; dh < 2; ++dh)
-                o[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[u & 1][dh], pf.v, o[dh], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // o[dh][r] = O[query r32][d = 32 dh + (r & 3) + 8 (r >> 2) + 4 hh]
-        if (q < T) {
-            const float inv = 1.0f / sum;
-            bf16_t* dst = out + ((size_t)b * T + q) * width + h * 64 + 4 * hh;
-#pragma unroll
-            for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    uint2 pk;
-                    pk.x = pack_bf16x2(o[dh][4 * rg] * inv, o[dh][4 * rg + 1] * inv);
-                    pk.y = pack_bf16x2(o[dh][4 * rg + 2] * inv, o[dh][4 * rg + 3] * inv);
-                    *(uint2*)(dst + 32 * dh + 8 * rg) = pk;
-                }
-        }
-    }
-}
-
-// ---- T = 257, eight waves per workgroup, key range in two halves (round 3, attn_v = 2) ------------------------------------------------
-// The PMC passes above say the waves WAIT: 1.4 waves per SIMD cannot hide the S^T -> softmax -> PV dependence of a tile.  This form
-// doubles the resident waves instead of rearranging a wave's instructions: eight waves share the K / V image of a head (two
-// workgroups per CU as before: 16 waves per CU, four per SIMD), which needs <= 128 VGPRs per wave -- so a tile's keys go in two
-// halves (10 + 8 key tiles of 16) with the running maximum / sum of an online softmax (textbook order: a half's scores are
-// exponentiated after the decision that covers them; o and l are rescaled by exp(m_old - m_new) once per half), 40 instead of 72
-// score registers.  257 queries = 2 x 8 tiles of 16, two per wave, balanced; the lone 257th query is split over the eight waves by
-// 32-key block (wave w: block w, wave 0 also the block that holds key 256) and merged through 2 KiB of LDS by wave 0.
-// Measured: 159 us against the 16-query kernel's 157 (same device, grid order): twice the waves finish tiles at the same rate per
-// SIMD -- see the note at the persistent kernel below for why.  Kept behind attn_v = 2 with its tests.
-struct AttnAcc { f32x4 o[4]; float m, l; };
-
-// one key range [t_lo, t_lo + NT) of 16-key tiles (NT even) for the 16 queries in qf; FIRST: acc is empty; MASK: keys >= T exist in it
-template <int NT, bool FIRST, bool MASK>
-__device__ __forceinline__ void attn_range(const bf16x8 (&qf)[2], int t_lo, int T, const char* sK, const char* sV, int lrow, int lq,
-                                           AttnAcc& a) {
-    constexpr float LOG2E = 1.4426950408889634f;
-    f32x4 s[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const char* kr = sK + ((t_lo + t) * 16 + lrow) * 128;
-        const bf16x8 k0 = *(const bf16x8*)(kr + ((lq ^ (lrow >> 1)) << 4));
-        const bf16x8 k1 = *(const bf16x8*)(kr + (((4 + lq) ^ (lrow >> 1)) << 4));
-        s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[0], s[t], 0, 0, 0);
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[1], s[t], 0, 0, 0);
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (MASK) s[t][r] = ((t_lo + t) * 16 + lq * 4 + r) < T ? s[t][r] : -INFINITY;
-            mx = fmaxf(mx, s[t][r]);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = FIRST ? mx : fmaxf(a.m, mx);          // finite: every range holds at least one real key
-    const float mxl = m_new * LOG2E;
-    f32x2_t sum2 = {0.f, 0.f};
-    const f32x2_t l2 = {LOG2E, LOG2E}, nm = {-mxl, -mxl};
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        f32x2_t x = f32x2_t{s[t][0], s[t][1]} * l2 + nm, y = f32x2_t{s[t][2], s[t][3]} * l2 + nm;
-        x.x = __builtin_amdgcn_exp2f(x.x); x.y = __builtin_amdgcn_exp2f(x.y);
-        y.x = __builtin_amdgcn_exp2f(y.x); y.y = __builtin_amdgcn_exp2f(y.y);
-        s[t][0] = x.x; s[t][1] = x.y; s[t][2] = y.x; s[t][3] = y.y;
-        sum2 += x;
-        sum2 += y;
-    }
-    if constexpr (FIRST) {
-        a.l = sum2.x + sum2.y;                                  // per-lane partial of the row sum: the four lanes of a row meet at the end
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) a.o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    } else {
-        const float alpha = __builtin_amdgcn_exp2f((a.m - m_new) * LOG2E);
-        a.l = a.l * alpha + (sum2.x + sum2.y);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) a.o[dt] *= alpha;
-    }
-    a.m = m_new;
-#pragma unroll
-    for (int u = 0; u < NT / 2; ++u) {
-        const int ra = (t_lo + 2 * u) * 16 + lq * 4 + (lrow >> 2), rb = ra + 16;
-        union { bf16x8 v; uint32_t w[4]; } pf;
-        pf.w[0] = pack_bf16x2(s[2 * u][0], s[2 * u][1]);
-        pf.w[1] = pack_bf16x2(s[2 * u][2], s[2 * u][3]);
-        pf.w[2] = pack_bf16x2(s[2 * u + 1][0], s[2 * u + 1][1]);
-        pf.w[3] = pack_bf16x2(s[2 * u + 1][2], s[2 * u + 1][3]);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int c = dt * 2 + ((lrow & 3) >> 1);
-            const bf16x4 va = lds_read_tr16(sV + ra * 128 + ((c ^ (((ra >> 1) & 3) << 1)) << 4) + (lrow & 1) * 8);
-            const bf16x4 vb = lds_read_tr16(sV + rb * 128 + ((c ^ (((rb >> 1) & 3) << 1)) << 4) + (lrow & 1) * 8);
-            bf16x8 vf;
-            vf[0] = va[0]; vf[1] = va[1]; vf[2] = va[2]; vf[3] = va[3];
-            vf[4] = vb[0]; vf[5] = vb[1]; vf[6] = vb[2]; vf[7] = vb[3];
-            a.o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf.v, a.o[dt], 0, 0, 0);
-        }
-    }
-}
-
-// the tail both eight-wave kernels share: the tiles of 16 queries this wave owns (wid and 8 + wid), its share of the lone 257th query,
-// the partials through sP; the caller's barrier follows, then attn_w8_merge by wave 0
-__device__ __forceinline__ void attn_w8_store(const AttnAcc& a, bf16_t* __restrict__ out, int b, int h, int q0, int width, int lrow, int lq) {
-    constexpr int T = 257;
-    float l = a.l;
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    const int q = q0 + lrow;
-    if (q < T) {
-        const float inv = 1.0f / l;
-        bf16_t* dst = out + ((size_t)b * T + q) * width + h * 64 + lq * 4;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            uint2 pk;
-            pk.x = pack_bf16x2(a.o[dt][0] * inv, a.o[dt][1] * inv);
-            pk.y = pack_bf16x2(a.o[dt][2] * inv, a.o[dt][3] * inv);
-            *(uint2*)(dst + dt * 16) = pk;
-        }
-    }
-}
-
-// NW = 8: two tiles per wave (wid and 8 + wid), partials of the lone query from 8 waves (wave 0 also takes block 8, where only key
-// 256 is real); NW = 16: one tile per wave, partials from waves 0 .. 8 (one 32-key block each).  NP = the number of partials.
-template <int NW>
-__device__ __forceinline__ void attn_w8_tiles(const bf16x8 (&qa)[2], const bf16x8 (&qb)[2], const bf16x8 (&ql)[2], const char* sK,
-                                              const char* sV, float* sP, bf16_t* __restrict__ out, int b, int h, int width, int wid,
-                                              int lrow, int lq) {
-    constexpr int T = 257;
-    AttnAcc acc;
-    attn_range<10, true, false>(qa, 0, T, sK, sV, lrow, lq, acc);
-    attn_range<8, false, true>(qa, 10, T, sK, sV, lrow, lq, acc);
-    attn_w8_store(acc, out, b, h, wid * 16, width, lrow, lq);
-    // (a compiler fence between the tiles: hipcc otherwise keeps the first tile's K / V fragments for the second one -- the same LDS
-    // addresses -- and, out of registers, spills them to scratch)
-    asm volatile("" ::: "memory");
-    if constexpr (NW == 8) {
-        attn_range<10, true, false>(qb, 0, T, sK, sV, lrow, lq, acc);
-        attn_range<8, false, true>(qb, 10, T, sK, sV, lrow, lq, acc);
-        attn_w8_store(acc, out, b, h, 128 + wid * 16, width, lrow, lq);
-        asm volatile("" ::: "memory");
-    }
-    // the 257th query: this wave's 32-key block
-    if (NW == 16 && wid > 8) return;                    // (uniform)
-    if (NW == 16 && wid == 8) attn_range<2, true, true>(ql, 16, T, sK, sV, lrow, lq, acc);
-    else attn_range<2, true, false>(ql, 2 * wid, T, sK, sV, lrow, lq, acc);
-    if (NW == 8 && wid == 0) attn_range<2, false, true>(ql, 16, T, sK, sV, lrow, lq, acc);
-    float l = acc.l;
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    if (lrow == 0) {                                    // column 0 = the query itself: lane (lq) holds d = dt*16 + lq*4 + r
-        float* dstp = sP + wid * 68;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) *(f32x4*)(dstp + dt * 16 + lq * 4) = acc.o[dt];
-        if (lq == 0) { dstp[64] = acc.m; dstp[65] = l; }
-    }
-}
-
-template <int NP>
-__device__ __forceinline__ void attn_w8_merge(const float* sP, bf16_t* __restrict__ out, int b, int h, int width, int lq) {
-    constexpr float LOG2E = 1.4426950408889634f;
-    float mx = -INFINITY;
-#pragma unroll
-    for (int w = 0; w < NP; ++w) mx = fmaxf(mx, sP[w * 68 + 64]);
-    float l = 0.f;
-    f32x4 o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < NP; ++w) {
-        const float f = __builtin_amdgcn_exp2f((sP[w * 68 + 64] - mx) * LOG2E);
-        l += sP[w * 68 + 65] * f;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] += *(const f32x4*)(sP + w * 68 + dt * 16 + lq * 4) * f;
-    }
-    const float inv = 1.0f / l;
-    bf16_t* dst = out + ((size_t)b * 257 + 256) * width + h * 64 + lq * 4;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        uint2 pk;
-        pk.x = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
-        pk.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
-        *(uint2*)(dst + dt * 16) = pk;
-    }
-}
-
-__global__ __launch_bounds__(512, 4) void attention_w8_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int width, int xbatch) {
-    constexpr int T = 257, TP = 288, NTH = 512, NCH = (TP * 8 + NTH - 1) / NTH;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;
-    char* sV = smem + TP * 128;
-    float* sP = (float*)(smem + 2 * TP * 128);          // partials of the lone query: 8 waves x (64 o + m + l), padded to 68 floats
-    int h, b;
-    if (!attn_item(xbatch, h, b)) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ld = 3 * width;
-    const bf16_t* base = qkv + (size_t)b * T * ld + h * 64;
-    const int lrow = lane & 15, lq = lane >> 4;
-    auto load_q = [&](int q0, bf16x8 (&qf)[2]) {
-        const int qc = q0 + lrow < T ? q0 + lrow : T - 1;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const bf16x8*)(base + (size_t)qc * ld + kk * 32 + lq * 8);
-    };
-    bf16x8 qa[2], qb[2], ql[2];
-    load_q(wid * 16, qa);
-    {
-        uint4 kv[NCH], vv[NCH];
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int idx = tid + i * NTH;
-            const int row = idx >> 3, c = idx & 7;
-            const int rc = row < T ? row : T - 1;
-            kv[i] = *(const uint4*)(base + (size_t)rc * ld + width + c * 8);
-            vv[i] = *(const uint4*)(base + (size_t)rc * ld + 2 * width + c * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int idx = tid + i * NTH;
-            const int row = idx >> 3, c = idx & 7;
-            if (idx < TP * 8) {
-                const unsigned keep = row < T ? 0xffffffffu : 0u;
-                uint4 a = kv[i], b2 = vv[i];
-                a.x &= keep; a.y &= keep; a.z &= keep; a.w &= keep;
-                b2.x &= keep; b2.y &= keep; b2.z &= keep; b2.w &= keep;
-                *(uint4*)(sK + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = a;
-                *(uint4*)(sV + row * 128 + ((c ^ (((row >> 1) & 3) << 1)) << 4)) = b2;
-            }
-        }
-    }
-    load_q(128 + wid * 16, qb);
-    load_q(256, ql);                                    // the lone query in every column (rows beyond it clamp to it)
-    __syncthreads();
-    attn_w8_tiles<8>(qa, qb, ql, sK, sV, sP, out, b, h, width, wid, lrow, lq);
-    __syncthreads();
-    if (wid == 0 && lrow == 0) attn_w8_merge<8>(sP, out, b, h, width, lq);
-}
-
-// ---- T = 257, two query tiles per pass sharing the K / V fragments (round 3 experiment, attn_v = 4) -------------------------------------
-// The 16-query kernel is bound per CU by LDS bytes (71.7 KB per tile) and by VALU + MFMA issue, not by its staging (notes at the persistent
-// kernel below).  Here a wave computes TWO query tiles at once through the key halves of the online softmax: every K fragment and every
-// transposed V fragment it reads from LDS feeds two MFMAs instead of one (half the LDS bytes per tile), and the two tiles are independent
-// instruction streams that hipcc may overlap.  Four waves per workgroup, two workgroups per CU as the 16-query kernel; 16 full tiles
-// = 8 pairs, two per wave; the lone 257th query split over the four waves by 32-key block and merged through LDS as in the eight-wave kernel.
-// Measured: 220 VGPRs, no scratch, correct at once (the tests of the other kernels), 153.5 - 155.3 us against 150.2 - 152.6 for the 16-query
-// kernel on the same box: half the LDS bytes per tile buy nothing either.  With the eight-wave kernel (twice the waves), the persistent
-// kernel (no staging phase), the pinned MFMA / exponential interleaving and this one, four different shapes of the same work land within
-// 5 % of each other, which says the launch is bound by what they share: per tile 72 quarter-rate exponentials and ~170 other VALU
-// instructions per lane, 72 MFMAs, and the q | k | v rows crossing the chip once.  Kept behind attn_v = 4 with its tests.
-template <int NT, bool FIRST, bool MASK>
-__device__ __forceinline__ void attn_range2(const bf16x8 (&qa)[2], const bf16x8 (&qb)[2], int t_lo, int T, const char* sK, const char* sV,
-                                            int lrow, int lq, AttnAcc& a, AttnAcc& b) {
-    constexpr float LOG2E = 1.4426950408889634f;
-    f32x4 sa[NT], sb[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const char* kr = sK + ((t_lo + t) * 16 + lrow) * 128;
-        const bf16x8 k0 = *(const bf16x8*)(kr + ((lq ^ (lrow >> 1)) << 4));
-        const bf16x8 k1 = *(const bf16x8*)(kr + (((4 + lq) ^ (lrow >> 1)) << 4));
-        sa[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        sb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qa[0], sa[t], 0, 0, 0);
-        sb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qb[0], sb[t], 0, 0, 0);
-        sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qa[1], sa[t], 0, 0, 0);
-        sb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qb[1], sb[t], 0, 0, 0);
-    }
-    auto soft = [&](f32x4 (&s)[NT], AttnAcc& acc) {
-        float mx = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (MASK) s[t][r] = ((t_lo + t) * 16 + lq * 4 + r) < T ? s[t][r] : -INFINITY;
-                mx = fmaxf(mx, s[t][r]);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = FIRST ? mx : fmaxf(acc.m, mx);
-        const float mxl = m_new * LOG2E;
-        f32x2_t sum2 = {0.f, 0.f};
-        const f32x2_t l2 = {LOG2E, LOG2E}, nm = {-mxl, -mxl};
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            f32x2_t x = f32x2_t{s[t][0], s[t][1]} * l2 + nm, y = f32x2_t{s[t][2], s[t][3]} * l2 + nm;
-            x.x = __builtin_amdgcn_exp2f(x.x); x.y = __builtin_amdgcn_exp2f(x.y);
-            y.x = __builtin_amdgcn_exp2f(y.x); y.y = __builtin_amdgcn_exp2f(y.y);
-            s[t][0] = x.x; s[t][1] = x.y; s[t][2] = y.x; s[t][3] = y.y;
-            sum2 += x;
-            sum2 += y;
-        }
-        if constexpr (FIRST) {
-            acc.l = sum2.x + sum2.y;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) acc.o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        } else {
-            const float alpha = __builtin_amdgcn_exp2f((acc.m - m_new) * LOG2E);
-            acc.l = acc.l * alpha + (sum2.x + sum2.y);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) acc.o[dt] *= alpha;
-        }
-        acc.m = m_new;
-    };
-    soft(sa, a);
-    soft(sb, b);
-#pragma unroll
-    for (int u = 0; u < NT / 2; ++u) {
-        const int ra = (t_lo + 2 * u) * 16 + lq * 4 + (lrow >> 2), rb = ra + 16;
-        union { bf16x8 v; uint32_t w[4]; } pa, pb;
-        pa.w[0] = pack_bf16x2(sa[2 * u][0], sa[2 * u][1]);
-        pa.w[1] = pack_bf16x2(sa[2 * u][2], sa[2 * u][3]);
-        pa.w[2] = pack_bf16x2(sa[2 * u + 1][0], sa[2 * u + 1][1]);
-        pa.w[3] = pack_bf16x2(sa[2 * u + 1][2], sa[2 * u + 1][3]);
-        pb.w[0] = pack_bf16x2(sb[2 * u][0], sb[2 * u][1]);
-        pb.w[1] = pack_bf16x2(sb[2 * u][2], sb[2 * u][3]);
-        pb.w[2] = pack_bf16x2(sb[2 * u + 1][0], sb[2 * u + 1][1]);
-        pb.w[3] = pack_bf16x2(sb[2 * u + 1][2], sb[2 * u + 1][3]);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int c = dt * 2 + ((lrow & 3) >> 1);
-            const bf16x4 va = lds_read_tr16(sV + ra * 128 + ((c ^ (((ra >> 1) & 3) << 1)) << 4) + (lrow & 1) * 8);
-            const bf16x4 vb = lds_read_tr16(sV + rb * 128 + ((c ^ (((rb >> 1) & 3) << 1)) << 4) + (lrow & 1) * 8);
-            bf16x8 vf;
-            vf[0] = va[0]; vf[1] = va[1]; vf[2] = va[2]; vf[3] = va[3];
-            vf[4] = vb[0]; vf[5] = vb[1]; vf[6] = vb[2]; vf[7] = vb[3];
-            a.o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pa.v, a.o[dt], 0, 0, 0);
-            b.o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb.v, b.o[dt], 0, 0, 0);
-        }
-    }
-}
-
-__global__ __launch_bounds__(256, 2) void attention_s2_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int width, int xbatch) {
-    constexpr int T = 257, TP = 288, NTH = 256, NCH = (TP * 8 + NTH - 1) / NTH;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;
-    char* sV = smem + TP * 128;
-    float* sP = (float*)(smem + 2 * TP * 128);          // partials of the lone query: 4 waves x (64 o + m + l), padded to 68 floats
-    int h, b;
-    if (!attn_item(xbatch, h, b)) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ld = 3 * width;
-    const bf16_t* base = qkv + (size_t)b * T * ld + h * 64;
-    const int lrow = lane & 15, lq = lane >> 4;
-    auto load_q = [&](int q0, bf16x8 (&qf)[2]) {
-        const int qc = q0 + lrow < T ? q0 + lrow : T - 1;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const bf16x8*)(base + (size_t)qc * ld + kk * 32 + lq * 8);
-    };
-    bf16x8 qa[2], qb[2];
-    load_q(wid * 32, qa);
-    load_q(wid * 32 + 16, qb);
-    {
-        uint4 kv[NCH], vv[NCH];
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int idx = tid + i * NTH;
-            const int row = idx >> 3, c = idx & 7;
-            const int rc = row < T ? row : T - 1;
-            kv[i] = *(const uint4*)(base + (size_t)rc * ld + width + c * 8);
-            vv[i] = *(const uint4*)(base + (size_t)rc * ld + 2 * width + c * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int idx = tid + i * NTH;
-            const int row = idx >> 3, c = idx & 7;
-            if (idx < TP * 8) {
-                const unsigned keep = row < T ? 0xffffffffu : 0u;
-                uint4 a = kv[i], b2 = vv[i];
-                a.x &= keep; a.y &= keep; a.z &= keep; a.w &= keep;
-                b2.x &= keep; b2.y &= keep; b2.z &= keep; b2.w &= keep;
-                *(uint4*)(sK + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = a;
-                *(uint4*)(sV + row * 128 + ((c ^ (((row >> 1) & 3) << 1)) << 4)) = b2;
-            }
-        }
-    }
-    __syncthreads();
-    AttnAcc accA, accB;
-#pragma unroll 1
-    for (int pr = 0; pr < 2; ++pr) {                    // pairs wid and 4 + wid: tiles 2 pair, 2 pair + 1
-        const int q0 = (pr * 4 + wid) * 32;
-        bf16x8 na[2], nb[2];
-        if (pr == 0) { load_q(q0 + 128, na); load_q(q0 + 144, nb); }       // the second pair's queries, ahead
-        attn_range2<10, true, false>(qa, qb, 0, T, sK, sV, lrow, lq, accA, accB);
-        attn_range2<8, false, true>(qa, qb, 10, T, sK, sV, lrow, lq, accA, accB);
-        attn_w8_store(accA, out, b, h, q0, width, lrow, lq);
-        attn_w8_store(accB, out, b, h, q0 + 16, width, lrow, lq);
-        asm volatile("" ::: "memory");
-        if (pr == 0) { qa[0] = na[0]; qa[1] = na[1]; qb[0] = nb[0]; qb[1] = nb[1]; }
-    }
-    // the 257th query: 32-key blocks w, w + 4 (and block 8, where only key 256 is real, on wave 0)
-    bf16x8 ql[2];
-    load_q(256, ql);
-    attn_range<2, true, false>(ql, 2 * wid, T, sK, sV, lrow, lq, accA);
-    attn_range<2, false, false>(ql, 2 * (wid + 4), T, sK, sV, lrow, lq, accA);
-    if (wid == 0) attn_range<2, false, true>(ql, 16, T, sK, sV, lrow, lq, accA);
-    {
-        float l = accA.l;
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
-        if (lrow == 0) {
-            float* dstp = sP + wid * 68;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) *(f32x4*)(dstp + dt * 16 + lq * 4) = accA.o[dt];
-            if (lq == 0) { dstp[64] = accA.m; dstp[65] = l; }
-        }
-    }
-    __syncthreads();
-    if (wid == 0 && lrow == 0) attn_w8_merge<4>(sP, out, b, h, width, lq);
-}
-
-// ---- T = 257, persistent, K / V of the next head by LDS-DMA while this one is computed (round 3, attn_v = 3) ---------------------------
-// One workgroup per CU walks a list of (image, head) items with two K / V buffers in LDS (2 x 72 KiB): the rows of item n + 1 are moved
-// by global_load_lds_dwordx4 (no registers, nothing for hipcc to schedule or to copy: with the prefetch held in 40 VGPRs it sank the
-// loads into the tiles and waited for each) while the tiles of item n are computed.  A DMA instruction fills 1 KiB = 8 rows; the lane
-// picks the global 16-byte chunk that belongs at its LDS slot (chunk = slot ^ swizzle(row), the swizzles above are involutions).  Pad
-// rows 257 .. 287 receive copies of row 256: a key >= T only occurs in the ranges that mask its score to -inf, so its V row meets
-// p = 0 and only has to be finite.  The DMA is issued from asm statements (M0 written in the statement that uses it, as in
-// gemm256u.hip), hipcc does not know of it: each wave waits for its own pieces (vmcnt(0)) before the barrier that opens the next
-// item.  Items are dealt so that XCD x (workgroups = x mod 8) takes the images = x (mod 8), as attn_item does for the other kernels.
-//
-// Measured (B = 255 x 16 heads, sustained, same device): 168 us with sixteen waves (one tile each), 186 us with eight (two tiles
-// each) against 150 us for the 16-query kernel with the images dealt to the XCDs (155 in grid order) and 159 us for the eight-wave
-// kernel above: the overlap of loading and computing buys nothing, because loading was never what the tiles waited for.  Probes of
-// the 16-query kernel on that launch (code removed again; each skips one thing, results wrong by construction): without the K / V
-// staging 112 us, the staging alone 43 us (HBM speed), together 157 us; without the LDS reads of the tiles 137 us, without the
-// exponentials 147 us, without the MFMAs 153 us; the second workgroup of every CU started 4 .. 16 us late: 158 - 162 us.  And the
-// rate of finished tiles per SIMD is the same with two waves per SIMD (16-query kernel) and with four (eight-wave kernel): one tile
-// per ~3 500 cycles.  That is the sum of what a tile issues on the SIMD -- ~1 800 cycles of VALU (67 quarter-rate v_exp_f32 are
-// 1 070 of them; PMC: SQ_ACTIVE_INST_VALU = 33 % of the launch) + 1 120 cycles of MFMA (70 x 16; SQ_VALU_MFMA_BUSY_CYCLES = 21 %)
-// + LDS waits -- not their maximum: within a wave S^T -> softmax -> PV is a dependence chain, and the waves of a SIMD, which all run
-// that same chain, overlap their MFMA and VALU phases only by accident (a persistent workgroup, whose waves leave a barrier
-// together, least of all: hence 168).  s_memtime stamps between the phases of the 16-query kernel (tools/prof_attention.py 10 stamps;
-// the instrumented build runs at the speed of the plain one) split a wave's life into 28 % staging (idle), 24 % S^T + K reads
-// (1 760 ticks per tile for 580 cycles of MFMA), 7 % mask + max, 14.5 % exponentials (1 050 per tile = 67 x 16: issue-bound), 19 %
-// PV + V reads (1 370 per tile for 580 of MFMA), 7 % normalise + store; 30.8 k ticks per wave against the 18.7 us of a workgroup slot read either as
-// a clock near 1.65 GHz or, at the GEMM's ~2.0 GHz, as ~3 us of dispatch and drain per slot.  At 1.65 GHz the tiles of a launch cost 120 us of VALU + MFMA issue per SIMD (no overlap) and 92 us of
-// LDS reads per CU (71.7 KB per tile at 128 B / clk; eight waves share one LDS): the tile phases run within ~10 % of both, i.e. the
-// kernel is near the limit of THIS shape of the work, and a faster one has to change the shape: K / V fragments shared by two
-// query tiles (half the LDS bytes) AND the two pipes overlapped inside one instruction stream (max(1 800, 1 120) instead of their
-// sum) AND the staging hidden -- each alone was tried and bought nothing or lost (attention32, the persistent kernel, and, on the
-// 16-query kernel: the exponentials of block u + 1 pinned between the PV MFMAs of block u with sched_group_barrier: 152 us
-// against 150, bit-identical; the next round's rows touched ahead into L2 by 4-byte LDS-DMA: staging 8.7 k -> 6.7 k ticks but
-// 164 us; every K load issued ahead of every V load, K written and the first tile's scores and softmax run while V is still on its
-// way, V written in front of that tile's PV phase: bit-identical, 152.3 against 151.2 us).  Kept behind attn_v = 3 with its tests.
-#define KEMR_ATTN_GLDS(VOFF, SBASE, LDSADDR) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" \
-                                                          :: "v"(VOFF), "s"(SBASE), "s"(LDSADDR) : "memory")
-template <int NW>                                       // waves per workgroup: 8 (two tiles each) or 16 (one tile each, <= 128 VGPRs)
-__global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void attention_pd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                                               int width, int batch) {
-    constexpr int T = 257, TP = 288, BUF = 2 * TP * 128, NPIECE = (72 + NW - 1) / NW, NP = NW == 16 ? 9 : 8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sP = (float*)(smem + 2 * BUF);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ld = 3 * width, heads = width >> 6;
-    // this workgroup is slot (blockIdx.x >> 3) of the gridDim.x / 8 slots of XCD blockIdx.x & 7, which owns the images xcd + 8 i
-    const int xcd = blockIdx.x & 7, nslot = gridDim.x >> 3;
-    const int nitem = ((batch - xcd + 7) >> 3) * heads;
-    int m = blockIdx.x >> 3;
-    if (m >= nitem) return;
-    auto item_base = [&](int mm, int& hh, int& bb) {
-        const int i = mm / heads;
-        hh = mm - i * heads; bb = xcd + 8 * i;
-        return qkv + (size_t)bb * T * ld + hh * 64;
-    };
-    // the wave's DMA pieces of an item: piece = wid + NW i of 72 (36 of K, then 36 of V), 8 rows each (the lane's offsets are
-    // formed again for every item: nine registers held across the tiles were the first ones hipcc spilled)
-    const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
-    auto stage = [&](const bf16_t* bs, unsigned buf, int ln) {
-#pragma unroll
-        for (int i = 0; i < NPIECE; ++i) {
-            const int piece = wid + NW * i;             // uniform
-            if (72 % NW != 0 && piece >= 72) break;
-            const int isv = piece >= 36;
-            const int row = (piece - 36 * isv) * 8 + (ln >> 3), slot = ln & 7;
-            const int chunk = isv ? slot ^ (((row >> 1) & 3) << 1) : slot ^ ((row >> 1) & 7);
-            const int rc = row < T ? row : T - 1;
-            const unsigned goff = (unsigned)((rc * ld + (1 + isv) * width + chunk * 8) * 2);
-            KEMR_ATTN_GLDS(goff, bs, lds0 + buf + (unsigned)(isv * TP * 128 + (piece - 36 * isv) * 1024));
-        }
-    };
-    auto load_q = [&](const bf16_t* bs, int q0, int lrow, int lq, bf16x8 (&qf)[2]) {
-        const int qc = q0 + lrow < T ? q0 + lrow : T - 1;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const bf16x8*)(bs + (size_t)qc * ld + kk * 32 + lq * 8);
-    };
-    int h, b;
-    const bf16_t* base = item_base(m, h, b);
-    bf16x8 qa[2], qb[2], ql[2], qn[2];
-    load_q(base, wid * 16, lane & 15, lane >> 4, qn);
-    stage(base, 0, lane);
-    unsigned buf = 0;
-    for (;;) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of item m (and qn) have landed ...
-        // (... which hipcc has to see for qn here, in front of the next loads: a wait of ITS counting for qn further down would
-        // cover the DMA pieces issued in between, which it does not count)
-        asm volatile("" : "+v"(qn[0]), "+v"(qn[1]));
-        __syncthreads();                                // ... everybody's have; and nobody reads the other buffer any more
-        // the lane id behind an empty asm, once per item: otherwise hipcc hoists every LDS address of the tiles out of the loop as an
-        // invariant and spills (464 bytes of scratch at 168 VGPRs, each reload a vmcnt(0) that drains the DMA)
-        int lane_o = lane;
-        asm volatile("" : "+v"(lane_o));
-        const int lrow = lane_o & 15, lq = lane_o >> 4;
-        qa[0] = qn[0]; qa[1] = qn[1];
-        const int mn = m + nslot;
-        const bool more = mn < nitem;                   // uniform
-        int hn = h, bn = b;
-        const bf16_t* nbase = base;
-        if (more) {
-            nbase = item_base(mn, hn, bn);
-            load_q(nbase, wid * 16, lrow, lq, qn);      // in front of the DMA: the first tile of the next item starts without a wait
-            stage(nbase, buf ^ BUF, lane_o);
-        }
-        if (NW == 8) load_q(base, 128 + wid * 16, lrow, lq, qb);     // behind it: their waits (second tile, lone query) let the DMA land first
-        load_q(base, 256, lrow, lq, ql);                // the lone query in every column (rows beyond it clamp to it)
-        attn_w8_tiles<NW>(qa, qb, ql, smem + buf, smem + buf + TP * 128, sP, out, b, h, width, wid, lrow, lq);
-        __syncthreads();                                // the partials are visible; every wave is done with this buffer
-        if (wid == 0 && lrow == 0) attn_w8_merge<NP>(sP, out, b, h, width, lq);
-        if (!more) break;
-        // (wave 0 merges before it reaches the barrier that opens the next item; the partials are written again only behind it)
-        m = mn; base = nbase; h = hn; b = bn;
-        buf ^= BUF;
-    }
-}
-
-// Measured (round 3, B = 255 x 16 heads, same device; profiles/r03_v2_attention_pmc.txt): 172 us against the 16-query kernel's 165.
-// Per launch it issues 11 % fewer VALU and 47 % fewer LDS instructions (23.9 M / 4.2 M against 26.8 M / 7.9 M) at the same MFMA
-// work, yet its waves spend 43 % of their cycles issue-stalled (SQ_WAIT_INST_ANY) where the 16-query kernel's spend 32 %: with 1.4
-// waves per SIMD on average neither hides the MFMA -> VALU -> MFMA dependence of a tile (S^T, softmax, PV), and the longer 32 x 32
-// chains expose more of it.  What is missing is a second tile in flight per wave, not fewer instructions.  Kept behind the
-// debug switch attn_v = 1 with its tests; the default stays the 16-query kernel.  (Also tried on the 16-query kernel and dropped: the
-// fences between its phases removed, mask + row maximum of key group g - 1 behind the MFMAs of group g, each 32-key block's
-// exponentials in the PV loop in front of the MFMAs that consume them -- hipcc hoists the exponentials, the kernel reaches 256
-// VGPRs with 28 bytes of scratch and takes 199-208 us against 178-184 on the same device.  A second tile in flight needs the
-// schedule written by hand, as the GEMM's is.)
-int g_attn_v = 0;          // tools, T = 257: 0 = the 16-query-tile kernel (default), 1 = 32-query tiles on the 32x32x16 MFMA, 2 = eight waves /
-                           // keys in two halves, 3 = 2 as a persistent workgroup per CU with the next head's K / V by LDS-DMA, 4 = two query
-                           // tiles per pass sharing the K / V fragments
+// The attention experiments of rounds 2-3 (32-query tiles on the 32x32x16 MFMA, eight waves, persistent LDS-DMA staging, two tiles
+// sharing fragments, six waves, the s_memtime-stamped build) live in attention_ab.hip / behind KEMR_AB_VARIANTS: they are built only
+// by `build.py --ab-variants`; the product library holds ONE attention kernel per shape and kemr_debug_set refuses the others.
+int g_attn_v = 0;          // A/B builds only (attention_ab.hip), T = 257: 0 = the product kernel, 1..4 = the experiments
 
 int g_attn_xcd = 1;        // 1 = the images dealt to the XCDs (attn_item above; default), 0 = grid order (tools)
 int g_attn_waves = 0;      // tools: 0 = the default choice below, else waves per workgroup for the 257-token shape (4 or 6)
 
-static int attention_num_cu(int* out) {                 // (as the persistent GEMM's: one process drives one device at a time)
-    static int cu_dev = -1, num_cu = 0;
-    int dev = 0;
-    KEMR_CHECK_HIP(hipGetDevice(&dev));
-    if (cu_dev != dev) {
-        KEMR_CHECK_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        cu_dev = dev;
-    }
-    *out = num_cu;
-    return KEMR_OK;
-}
+#ifdef KEMR_AB_VARIANTS
+int launch_attention_ab(int v, int waves, const bf16_t* qkv, bf16_t* out, int batch, int width, int xbatch, hipStream_t stream);
+#endif
 
 template <int NT32>
 static int launch_nt(const bf16_t* qkv, bf16_t* out, int batch, int t, int width, int causal, hipStream_t stream, const int* row_start = nullptr) {
@@ -992,41 +289,18 @@ static int launch_nt(const bf16_t* qkv, bf16_t* out, int batch, int t, int width
     if (causal) {
         if (NT32 == 3 && t == 77 && !row_start) { kern = attention_kernel<NT32, true, NT32 == 3 ? 77 : 0, NT32 == 3 ? 5 : 4>; threads = 320; }
         else kern = attention_kernel<NT32, true, 0>;
-    } else if (NT32 == 9 && t == 257 && g_attn_v >= 2) {
-        if (g_attn_v == 4) {
-            constexpr int smem2 = 2 * 288 * 128 + 4 * 68 * 4;
-            KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)attention_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem2));
-            hipLaunchKernelGGL(attention_s2_kernel, xgrid, dim3(256), smem2, stream, qkv, out, width, xbatch);
-        } else if (g_attn_v == 3) {
-            constexpr int smemp = 4 * 288 * 128 + 9 * 68 * 4;
-            int num_cu = 0;
-            if (int rc = attention_num_cu(&num_cu)) return rc;
-            const int pgrid = num_cu >= 8 ? num_cu / 8 * 8 : 8;      // slots per XCD = grid / 8
-            if (g_attn_waves == 8) {
-                KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)attention_pd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, smemp));
-                hipLaunchKernelGGL(attention_pd_kernel<8>, dim3(pgrid), dim3(512), smemp, stream, qkv, out, width, batch);
-            } else {
-                KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)attention_pd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, smemp));
-                hipLaunchKernelGGL(attention_pd_kernel<16>, dim3(pgrid), dim3(1024), smemp, stream, qkv, out, width, batch);
-            }
-        } else {
-            constexpr int smem8 = 2 * 288 * 128 + 8 * 68 * 4;
-            KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)attention_w8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem8));
-            hipLaunchKernelGGL(attention_w8_kernel, xgrid, dim3(512), smem8, stream, qkv, out, width, xbatch);
-        }
-        KEMR_CHECK_LAUNCH("attention_w8_kernel");
-        return KEMR_OK;
-    } else if (NT32 == 9 && t == 257 && g_attn_v == 1) {
-        auto k32 = attention32_kernel<4>;
-        KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)k32, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        hipLaunchKernelGGL(k32, grid, dim3(256), smem, stream, qkv, out, width);
-        KEMR_CHECK_LAUNCH("attention32_kernel");
-        return KEMR_OK;
     } else if (NT32 == 9 && t == 257) {
+#ifdef KEMR_AB_VARIANTS
+        if (g_attn_v != 0) return launch_attention_ab(g_attn_v, g_attn_waves, qkv, out, batch, width, xbatch, stream);
         if (g_attn_waves == 6) { kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, NT32 == 9 ? 6 : 4>; threads = 384; }
         else if (g_attn_waves == 2 && xbatch) kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, 4, NT32 == 9>;   // stamps: the caller's
                                                                                                                          // `out` has room behind it
-        else kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0>;
+        else
+#else
+        if (g_attn_v != 0 || g_attn_waves != 0)
+            KEMR_FAIL(KEMR_ERR_INVALID, "attention: attn_v = %d / attn_waves = %d select A/B kernels this library was built without (build.py --ab-variants)", g_attn_v, g_attn_waves);
+#endif
+        kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0>;
     } else {
         kern = attention_kernel<NT32, false, 0>;
     }
@@ -1063,6 +337,12 @@ int launch_attention(const bf16_t* qkv, bf16_t* out, int batch, int t, int width
 // the 1/sqrt(64) lives in the packed q weights); k, v: the qkv buffer of the whole call (ld 3 * width); out: [items, width] compact.
 // Item b's keys are the rows key0[b] .. key0[b] + nkeys[b] - 1, taken from pool_idx / row_start:
 //   vision (causal = 0): all `tokens` rows from b * tokens;  text: the rows from the text's first up to the pooled one.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ __launch_bounds__(256) void attention_pooled_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ qkv,
                                                                bf16_t* __restrict__ out, const int* __restrict__ pool_idx,
                                                                const int* __restrict__ row_start, int items, int tokens, int width,
@@ -1109,7 +389,9 @@ __global__ __launch_bounds__(256) void attention_pooled_kernel(const bf16_t* __r
         s += __shfl_xor(s, 4);
         if (ck == 0 && j < nk) sp[wv][j] = s;
     }
-    // softmax over the wave's LDS row (written and read by this wave only; a wave's LDS accesses stay in order)
+    // softmax over the wave's LDS row, written and read by this wave only: the hardware keeps a wave's LDS accesses in order, the
+    // fence + wave barrier keep the COMPILER from moving a lane's loads above another lane's stores it cannot prove to alias
+    wave_lds_fence();
     float sc[MAXK / 64];
     float mx = -INFINITY;
 #pragma unroll
@@ -1130,7 +412,7 @@ __global__ __launch_bounds__(256) void attention_pooled_kernel(const bf16_t* __r
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    // (the wave's own LDS row: written and read by this wave only; the compiler orders LDS accesses of a wave by lgkmcnt)
+    wave_lds_fence();                                    // the bf16-rounded P row: stores of all lanes before any lane's loads
     const int dp = lane & 31, par = lane >> 5;
     const bf16_t* vp = qkv + (size_t)r0 * ld + 2 * width + h * 64 + dp * 2;
     float a0 = 0.f, a1 = 0.f;

@@ -383,18 +383,25 @@ __global__ __launch_bounds__(512, 2) void gemm256s_bf16_nt_kernel(const GemmPara
 template <int EPI>
 static int launch256(const GemmParams& p, hipStream_t stream) {
     constexpr int smem = 2 * TBUF;
-    auto kern_lock = gemm256_bf16_nt_kernel<EPI>;      // default (variant 2): one barrier per phase, waves in lockstep
-    auto kern_stag = gemm256s_bf16_nt_kernel<EPI>;     // variant 3: staggered wave halves (measured 1-9 % slower, kept for A/B)
+    auto kern_lock = gemm256_bf16_nt_kernel<EPI>;      // the product kernel (variant 2): one barrier per phase, waves in lockstep
+#ifdef KEMR_AB_VARIANTS
+    auto kern_stag = gemm256s_bf16_nt_kernel<EPI>;     // variant 3: staggered wave halves (measured 1-9 % slower; A/B builds only)
+#endif
     static bool attr_done = false;
     if (!attr_done) {
         KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern_lock, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+#ifdef KEMR_AB_VARIANTS
         KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern_stag, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+#endif
         attr_done = true;
     }
     const int tiles = ((p.M + 255) / 256) * (p.N / 256);
     ProfScope prof(PROF_GEMM, stream);
+#ifdef KEMR_AB_VARIANTS
     if (g_gemm_variant == 3) hipLaunchKernelGGL(kern_stag, dim3(tiles), dim3(512), smem, stream, p);
-    else { GemmParams q = p; q.dbg = g_gemm_dbg; hipLaunchKernelGGL(kern_lock, dim3(tiles), dim3(512), smem, stream, q); }
+    else
+#endif
+    { GemmParams q = p; q.dbg = g_gemm_dbg; hipLaunchKernelGGL(kern_lock, dim3(tiles), dim3(512), smem, stream, q); }
     KEMR_CHECK_LAUNCH("gemm256_bf16_nt_kernel");
     return KEMR_OK;
 }

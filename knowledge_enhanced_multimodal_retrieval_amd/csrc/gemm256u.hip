@@ -1127,15 +1127,17 @@ static int launch256u(const GemmParams& p, hipStream_t stream) {
         if (conc) return launch256u_a<EPI, true, false, true>(p, stream);
         return launch256u_a<EPI, true, false, false>(p, stream);
     } else {
-        if (g_gemm_dbg) {                         // tools/: the stamped / timing-experiment instantiation, for either K loop
+#ifdef KEMR_AB_VARIANTS                            // tools/ only (build.py --ab-variants); kemr_debug_set refuses both switches otherwise
+        if (g_gemm_dbg) {                         // the stamped / timing-experiment instantiation, for either K loop
             if (g_gemm_kl) return launch256u_a<EPI, false, true, false, true>(p, stream);
             if (conc) return launch256u_a<EPI, false, true, true>(p, stream);
             return launch256u_a<EPI, false, true, false>(p, stream);
         }
-        if (g_gemm_kl) {                          // tools/: the long-interval K loop for A/B timing
+        if (g_gemm_kl) {                          // the long-interval K loop for A/B timing
             if (conc) return launch256u_a<EPI, false, false, true, true>(p, stream);
             return launch256u_a<EPI, false, false, false, true>(p, stream);
         }
+#endif
         if (conc) return launch256u_a<EPI, false, false, true>(p, stream);
         return launch256u_a<EPI, false, false, false>(p, stream);
     }
@@ -1195,12 +1197,14 @@ static int launch_sim_mode_a(const GemmParams& p, int q_tiles, hipStream_t strea
 
 template <int SIM>
 static int launch_sim_mode(const GemmParams& p, int q_tiles, hipStream_t stream) {
+#ifdef KEMR_AB_VARIANTS
     if constexpr (SIM != 3) {
         if (g_gemm_dbg & (64 | 128)) return launch_sim_mode_a<SIM, true>(p, q_tiles, stream);      // tools: stamped instantiation
     }
     if constexpr (SIM == 2) {
         if (g_gemm_kl) return launch_sim_mode_a<SIM, false, true>(p, q_tiles, stream);      // tools/: long-interval K loop, A/B timing
     }
+#endif
     return launch_sim_mode_a<SIM, false>(p, q_tiles, stream);
 }
 
@@ -1285,7 +1289,9 @@ int launch_gemm256u(const GemmParams& p, int epi, hipStream_t stream) {
         case EPI_BIAS_QGELU_BF16: return launch256u<EPI_BIAS_QGELU_BF16, false>(p, stream);
         case EPI_BIAS_RESADD_BF16: return launch256u_a<EPI_BIAS_RESADD_BF16, false, false, false>(p, stream);
         case EPI_BIAS_RESID_F32:
+#ifdef KEMR_AB_VARIANTS
             if (g_gemm_kl) return launch256u_a<EPI_BIAS_RESID_F32, false, false, false, true>(p, stream);
+#endif
             return launch256u_a<EPI_BIAS_RESID_F32, false, false, false>(p, stream);
     }
     KEMR_FAIL(KEMR_ERR_INVALID, "gemm256u: epilogue %d is not one of this kernel's", epi);

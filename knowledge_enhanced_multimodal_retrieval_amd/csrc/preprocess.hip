@@ -175,7 +175,8 @@ struct PreImg {
     int width, row_lo, rows, left, top;
     int ksize_h, resample_h, ksize_v, resample_v;
     int tab_hk, tab_hb, tab_vk, tab_vb;      // int32 offsets of its plan's tables in the table area
-    int pad;
+    int zero_out;          // 1: an item the caller could not decode (height = width = 0): its output is 0.0f AFTER normalisation,
+                           // what the reference's dataset feeds the encoder then (clip_dataset.py:120-125: torch.zeros(3, 224, 224))
 };
 static_assert(sizeof(PreImg) == 72, "descriptor layout");
 
@@ -212,6 +213,12 @@ __global__ __launch_bounds__(256) void preprocess_v_batch_kernel(const PreImg* _
     if (gid >= n * n) return;
     const int yy = gid / n, xx = gid - yy * n;
     const uint8_t* temp = temp_all + d.temp_off;
+    const size_t plane = (size_t)n * n;
+    float* out = out_all + (size_t)blockIdx.y * 3 * plane;
+    if (d.zero_out) {
+        out[gid] = 0.0f; out[plane + gid] = 0.0f; out[2 * plane + gid] = 0.0f;
+        return;
+    }
     int v0, v1, v2;
     if (!d.resample_v) {
         const uint8_t* s = temp + ((size_t)(d.top + yy - d.row_lo) * n + xx) * 3;
@@ -228,8 +235,6 @@ __global__ __launch_bounds__(256) void preprocess_v_batch_kernel(const PreImg* _
         }
         v0 = clip8(s0 >> PRECISION_BITS); v1 = clip8(s1 >> PRECISION_BITS); v2 = clip8(s2 >> PRECISION_BITS);
     }
-    const size_t plane = (size_t)n * n;
-    float* out = out_all + (size_t)blockIdx.y * 3 * plane;
     out[gid] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)v0, 255.0f), m0), d0);
     out[plane + gid] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)v1, 255.0f), m1), d1);
     out[2 * plane + gid] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)v2, 255.0f), m2), d2);
@@ -273,6 +278,14 @@ int layout_batch(const int32_t* heights, const int32_t* widths, const int64_t* o
     size_t temp = 0;
     for (int b = 0; b < batch; ++b) {
         const int h = heights[b], w = widths[b];
+        if (h == 0 && w == 0) {                  // undecodable item: no input bytes, zeros out (PreImg::zero_out)
+            PreImg& d = L.desc[b];
+            memset(&d, 0, sizeof(d));
+            d.img_off = offsets ? offsets[b] : 0;
+            d.temp_off = (long long)temp;
+            d.zero_out = 1;
+            continue;
+        }
         if (h <= 0 || w <= 0 || h > 32768 || w > 32768) KEMR_FAIL(KEMR_ERR_INVALID, "preprocess batch: bad image size %d x %d (image %d)", h, w, b);
         const Plan& p = plan_for(h, w, n);
         auto it = seen.find({h, w});
@@ -287,7 +300,7 @@ int layout_batch(const int32_t* heights, const int32_t* widths, const int64_t* o
         d.width = w; d.row_lo = p.vy.in_lo; d.rows = p.vy.in_hi - p.vy.in_lo; d.left = p.left; d.top = p.top;
         d.ksize_h = p.hx.ksize; d.resample_h = p.hx.resample ? 1 : 0; d.ksize_v = p.vy.ksize; d.resample_v = p.vy.resample ? 1 : 0;
         d.tab_hk = it->second[0]; d.tab_hb = it->second[1]; d.tab_vk = it->second[2]; d.tab_vb = it->second[3];
-        d.pad = 0;
+        d.zero_out = 0;
         temp += (size_t)round_up((int64_t)d.rows * n * 3, 16);
         if (d.rows > L.max_rows) L.max_rows = d.rows;
     }
@@ -314,10 +327,11 @@ extern "C" int kemr_preprocess_u8_batch(const unsigned char* packed_dev, const i
                                         const int32_t* widths, int batch, int n_px, float* out_dev, void* workspace_dev,
                                         size_t workspace_bytes, void* stream) {
     if (batch == 0) return KEMR_OK;
-    if (!packed_dev || !offsets || !heights || !widths || !out_dev || batch < 0) KEMR_FAIL(KEMR_ERR_INVALID, "preprocess batch: null argument");
+    if (!offsets || !heights || !widths || !out_dev || batch < 0) KEMR_FAIL(KEMR_ERR_INVALID, "preprocess batch: null argument");
     if (n_px <= 0 || n_px > 1024) KEMR_FAIL(KEMR_ERR_INVALID, "preprocess batch: bad output size %d", n_px);
     BatchLayout L;
     KEMR_TRY(layout_batch(heights, widths, offsets, batch, n_px, L));
+    if (!packed_dev && L.max_rows > 0) KEMR_FAIL(KEMR_ERR_INVALID, "preprocess batch: null image buffer");
     if (!workspace_dev || workspace_bytes < L.bytes) KEMR_FAIL(KEMR_ERR_WORKSPACE, "preprocess batch: workspace too small: %zu < %zu bytes", workspace_bytes, L.bytes);
     if ((uintptr_t)workspace_dev % 256) KEMR_FAIL(KEMR_ERR_WORKSPACE, "preprocess batch: workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
@@ -334,9 +348,11 @@ extern "C" int kemr_preprocess_u8_batch(const unsigned char* packed_dev, const i
     KEMR_CHECK_HIP(hipEventRecord(done, s));
     const int n = n_px;
     ProfScope prof(PROF_OTHER, s);
-    hipLaunchKernelGGL(preprocess_h_batch_kernel, dim3((unsigned)(((size_t)L.max_rows * n + 255) / 256), (unsigned)batch), dim3(256), 0, s,
-                       packed_dev, (const PreImg*)ws, (const int32_t*)(ws + L.tab_off), (uint8_t*)(ws + L.temp_off), n);
-    KEMR_CHECK_LAUNCH("preprocess_h_batch_kernel");
+    if (L.max_rows > 0) {                        // 0: every item of the batch is a zero_out item
+        hipLaunchKernelGGL(preprocess_h_batch_kernel, dim3((unsigned)(((size_t)L.max_rows * n + 255) / 256), (unsigned)batch), dim3(256), 0, s,
+                           packed_dev, (const PreImg*)ws, (const int32_t*)(ws + L.tab_off), (uint8_t*)(ws + L.temp_off), n);
+        KEMR_CHECK_LAUNCH("preprocess_h_batch_kernel");
+    }
     hipLaunchKernelGGL(preprocess_v_batch_kernel, dim3((unsigned)((n * n + 255) / 256), (unsigned)batch), dim3(256), 0, s,
                        (const PreImg*)ws, (const int32_t*)(ws + L.tab_off), (const uint8_t*)(ws + L.temp_off), n, 0.48145466f, 0.4578275f,
                        0.40821073f, 0.26862954f, 0.26130258f, 0.27577711f, out_dev);

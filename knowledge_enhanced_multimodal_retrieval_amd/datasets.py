@@ -51,8 +51,11 @@ class CLIPEvalDatasetHF(Dataset):
         except Exception as e:  # undecodable image -> zero image, like the reference (clip_dataset.py:120-125)
             logger.error(f"Error loading image {sample.get('uuid', idx)}: {e}")
             if self.preprocessor:
+                # The reference substitutes torch.zeros(3, 224, 224): zeros AFTER normalisation.  On the raw route that is an
+                # EMPTY uint8 [0, 0, 3] item, which pack_raw / kemr_preprocess_u8_batch turn into that same all-zero tensor
+                # (a black uint8 picture would normalise to (-1.79, -1.75, -1.48) and give a different embedding).
                 from .preprocess import RawRGB
-                image = (torch.zeros(self.image_size, self.image_size, 3, dtype=torch.uint8) if isinstance(self.preprocessor, RawRGB)
+                image = (torch.zeros(0, 0, 3, dtype=torch.uint8) if isinstance(self.preprocessor, RawRGB)
                          else torch.zeros(3, self.image_size, self.image_size))
             else:
                 from PIL import Image

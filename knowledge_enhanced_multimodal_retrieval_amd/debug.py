@@ -14,6 +14,12 @@ from . import _lib
 KEYS = ("gemm_variant", "gemm_flags", "gemm_order", "gemm_conc", "gemm_kl", "attn_v", "attn_xcd", "attn_waves", "sim_lists")
 
 
+def ab_variants() -> bool:
+    """True when libkemr.so was built with the experiment kernels (``build.py --ab-variants``); the product library refuses the
+    switch values that select them."""
+    return get("ab_variants") == 1
+
+
 def set(key: str, value: int) -> None:      # noqa: A001 (module-level verb of a tiny module)
     _lib.check(_lib.lib().kemr_debug_set(key.encode(), int(value)), f"debug_set({key})")
 

@@ -190,8 +190,17 @@ class ClipEngine:
         if not self.ready:
             raise RuntimeError("ClipEngine: load_state_dict() must be called before encoding")
         pack = self.pack_text and a.ctx <= 128
-        if pack and lens is None and not ids.is_cuda:
-            lens = text_lengths(ids)
+        if pack and not ids.is_cuda:
+            # host ids: the lengths are free to compute; caller-supplied ones may only LENGTHEN a text (a length short of the
+            # end-of-text token would pool the wrong row: ADVICE r3)
+            own = text_lengths(ids)
+            if lens is None:
+                lens = own
+            else:
+                given = torch.as_tensor(lens, device="cpu").reshape(-1).to(own.dtype)
+                if given.numel() != own.numel():
+                    raise RuntimeError(f"encode_text: {given.numel()} lengths for {own.numel()} texts")
+                lens = torch.maximum(given, own)
         ids = ids.to(device=self.device, dtype=torch.int32, non_blocking=True).contiguous()
         _require_cuda(ids, "token ids")
         if pack and lens is None and os.environ.get("KEMR_TEXT_PACK_SYNC", "1") != "0":

@@ -96,12 +96,41 @@ def loader_context():
     return ctx
 
 
+def _local_world_size() -> int:
+    for key in ("LOCAL_WORLD_SIZE", "WORLD_SIZE"):
+        v = os.environ.get(key, "")
+        if v.strip().isdigit() and int(v) > 0:
+            return int(v)
+    return 1
+
+
+def usable_loader_workers(dataset, collate, num_workers: int) -> int:
+    """Worker processes the loader can actually be given.  They come from a fork server (loader_context), which PICKLES the
+    dataset and the collate object; the reference's loaders fork (evaluator_baseline.py:83-92) and therefore accept lambdas,
+    closures and in-memory objects.  A caller who passes such a dataset / tokenize_fn gets num_workers = 0 and a warning
+    instead of a crash inside DataLoader; under torchrun the count is divided by the local world size."""
+    if num_workers <= 0:
+        return 0
+    num_workers = max(1, num_workers // _local_world_size())
+    if os.environ.get("KEMR_LOADER_CONTEXT", "forkserver") == "fork":
+        return num_workers
+    import io
+    import pickle
+    try:
+        pickle.dump((dataset, collate), io.BytesIO(), protocol=pickle.HIGHEST_PROTOCOL)
+    except Exception as e:                                     # noqa: BLE001 - anything that cannot cross to a fresh process
+        logger.warning(f"loader workers need a picklable dataset / tokenize_fn ({type(e).__name__}: {e}); using num_workers=0")
+        return 0
+    return num_workers
+
+
 def eval_loader(dataset, batch_size: int, seed: int, num_workers: int, tokenize_fn: Callable, pin: bool) -> DataLoader:
     """The evaluation DataLoader (evaluator.py:96-105: no shuffle, seeded workers), with tokenisation and the packing of raw
     images into one buffer moved INTO the loader (its worker processes when there are any); the pin thread pins both.
     What is left on the consumer's thread per loader batch: three asynchronous copies and the kernel launches."""
     g = torch.Generator()
     g.manual_seed(seed)
+    num_workers = usable_loader_workers(dataset, CollateAndTokenize(tokenize_fn), num_workers)
     return DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers, pin_memory=pin,
                       collate_fn=CollateAndTokenize(tokenize_fn), worker_init_fn=seed_worker if num_workers else None,
                       generator=g, prefetch_factor=4 if num_workers else None,
@@ -218,11 +247,12 @@ def sparql_sweep(query, target, image, uuids, text2sparql_results, t2i_weight, t
 @torch.no_grad()
 def evaluate_clip_model(model, dataset, batch_size: int = 64, device: str = "cuda", seed: int = 42,
                         tasks: List[str] = ("T2I", "I2T", "T2T"), compute_recall: bool = True, compute_mrr: bool = True,
-                        tokenize_fn: Optional[Callable] = None, num_workers: Optional[int] = None,
+                        tokenize_fn: Optional[Callable] = None, num_workers: Optional[int] = 0,
                         text2sparql_results: Optional[Dict[str, List[str]]] = None, analysis: bool = True
                         ) -> Dict[str, float]:
     """evaluator.py semantics: per-task metrics are returned; the fused / SPARQL-sweep analysis is logged and kept in
-    ``evaluate_clip_model.last_analysis``."""
+    ``evaluate_clip_model.last_analysis``.  ``num_workers`` defaults to the reference's 0 (evaluator.py:101); the CLIs opt into
+    ``default_loader_workers()``, a library caller passes a number (None = that default)."""
     image, query, target, uuids = encode_dataset(model, dataset, batch_size, seed, num_workers, tokenize_fn)
     logger.info(f"Image embeddings: {tuple(image.shape)}")
     logger.info(f"Query embeddings: {tuple(query.shape)}")
@@ -253,8 +283,9 @@ def evaluate_clip_model_for_training(model, dataset, batch_size: int = 64, devic
 def evaluate_clip_model_baseline(model, dataset, batch_size: int = 64, device: str = "cuda", seed: int = 42,
                                  tasks: List[str] = ("T2I", "I2T", "T2T"), compute_recall: bool = True,
                                  compute_mrr: bool = True, t2i_weight: float = 0.5, t2t_weight: float = 0.5,
-                                 tokenize_fn: Optional[Callable] = None, num_workers: Optional[int] = None) -> Dict[str, float]:
-    """evaluator_baseline.py semantics: metrics of the fused score w_i * T2I + w_t * T2T (un-prefixed keys)."""
+                                 tokenize_fn: Optional[Callable] = None, num_workers: Optional[int] = 4) -> Dict[str, float]:
+    """evaluator_baseline.py semantics: metrics of the fused score w_i * T2I + w_t * T2T (un-prefixed keys); 4 loader workers
+    as there (evaluator_baseline.py:87)."""
     image, query, target, _ = encode_dataset(model, dataset, batch_size, seed, num_workers, tokenize_fn)
     return M.compute_retrieval_metrics_final(query, target, image, compute_recall=compute_recall, compute_mrr=compute_mrr,
                                              t2i_weight=t2i_weight, t2t_weight=t2t_weight)
@@ -359,8 +390,8 @@ def main_baseline(argv=None):
 # ------------------------------------------------------------------------------------------------ learned fusion heads
 @torch.no_grad()
 def evaluate_fusion_model(fusion_model, dataset, batch_size: int = 64, device: str = "cuda", seed: int = 42,
-                          tokenize_fn: Optional[Callable] = None, num_workers: Optional[int] = None) -> Dict[str, float]:
-    """Counterpart of /root/reference/src/clip/eval/evaluator_fusion.py:28-144.  The reference fills an N x N numpy
+                          tokenize_fn: Optional[Callable] = None, num_workers: Optional[int] = 4) -> Dict[str, float]:
+    """Counterpart of /root/reference/src/clip/eval/evaluator_fusion.py:28-144 (4 loader workers as at :42).  The reference fills an N x N numpy
     matrix in 50 x 500 blocks with an H2D/D2H round trip and ``empty_cache()`` per block (:76-121); here the head's
     score is one fused kernel pass over resident embeddings (``FusionModel.rank``)."""
     fusion_model.eval()

@@ -71,6 +71,8 @@ class ClipPreprocessGPU:
             raise RuntimeError(f"ClipPreprocessGPU expects uint8 [H, W, 3], got {image.dtype} {tuple(image.shape)}")
         img = image.to(self.device).contiguous()
         h, w = int(img.shape[0]), int(img.shape[1])
+        if h == 0 and w == 0:          # an undecodable item (datasets.CLIPEvalDatasetHF): zeros after normalisation, as the reference
+            return torch.zeros((3, self.n_px, self.n_px), dtype=torch.float32, device=self.device)
         L = _lib.lib()
         need = int(L.kemr_preprocess_workspace_bytes(h, w, self.n_px))
         if need == 0:
@@ -142,6 +144,15 @@ class PackedRaw:
 
     def pin_memory(self, device=None):            # the DataLoader's pin thread calls this on custom batch types
         return PackedRaw(self.data.pin_memory(), self._h, self._w)
+
+    def to(self, device=None, non_blocking: bool = False, **_kw):
+        """``images.to(device)`` of the reference's loop (evaluator.py:118): the pixel bytes move, the sizes stay host arrays.
+        ``CLIP.encode_image`` accepts the result (it runs :meth:`ClipPreprocessGPU.batch` first)."""
+        return PackedRaw(self.data.to(device, non_blocking=non_blocking), self._h, self._w)
+
+    @property
+    def shape(self):                               # (B,): enough for ``images.shape[0]`` bookkeeping
+        return (len(self),)
 
 
 def pack_raw(images) -> PackedRaw:

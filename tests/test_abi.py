@@ -7,7 +7,7 @@ import subprocess
 
 import pytest
 
-from knowledge_enhanced_multimodal_retrieval_amd import _lib
+from knowledge_enhanced_multimodal_retrieval_amd import _lib, debug
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -64,14 +64,35 @@ def test_model_options_and_debug_switches_are_separate():
     assert before["gemm_variant"] == 0 and before["gemm_kl"] == 0 and before["sim_lists"] == 1
     with debug.override(gemm_order=0, gemm_variant=2):
         assert debug.get("gemm_order") == 0 and debug.get("gemm_variant") == 2 and debug.get("gemm_conc") == before["gemm_conc"]
-        debug.set_gemm_variant(7 | (64 << 8))                     # the packed form touches variant and flags only ...
-        assert debug.get("gemm_variant") == 7 and debug.get("gemm_flags") == 64 and debug.get("gemm_order") == 0
+        debug.set_gemm_variant(7 | (1 << 16))                     # the packed form touches variant and flags (and what else is non-zero) only ...
+        assert debug.get("gemm_variant") == 7 and debug.get("gemm_flags") == 0 and debug.get("gemm_order") == 0
         debug.set_gemm_variant(0)
     assert {k: debug.get(k) for k in debug.KEYS} == before
     with pytest.raises(RuntimeError, match="unknown key"):
         debug.set("gemm_nope", 1)
     with pytest.raises(RuntimeError, match="not in"):
         debug.set("gemm_variant", 12)
+    with pytest.raises(RuntimeError, match="read-only"):
+        debug.set("ab_variants", 1)
+
+
+def test_product_library_refuses_the_experiment_kernels():
+    """the default libkemr.so holds one attention kernel per shape and one K loop; the switch values that select
+    the experiments of rounds 1-3 exist only in a `build.py --ab-variants` library and are refused here."""
+    if debug.ab_variants():
+        pytest.skip("this libkemr.so was built with --ab-variants")
+    for key, value in (("attn_v", 1), ("attn_v", 4), ("attn_waves", 6), ("gemm_kl", 1), ("gemm_variant", 3), ("gemm_variant", 4),
+                       ("gemm_variant", 9), ("gemm_flags", 64)):
+        with pytest.raises(RuntimeError, match="A/B experiment kernel"):
+            debug.set(key, value)
+        assert debug.get(key) == 0
+    for key, value in (("gemm_variant", 1), ("gemm_variant", 2), ("gemm_variant", 7), ("gemm_variant", 8), ("attn_xcd", 0), ("sim_lists", 3)):
+        with debug.override(**{key: value}):
+            assert debug.get(key) == value
+    syms = open(_lib.LIB_PATH, "rb").read()                     # host stubs AND the gfx950 code objects carry the kernels' names
+    for name in ("attention32_kernel", "attention_w8_kernel", "attention_s2_kernel", "attention_pd_kernel", "gemm256s_bf16_nt_kernel",
+                 "gemm256p", "gemm256q", "gemm256w", "gemm256r"):
+        assert name.encode() not in syms, name
 
 
 def test_no_torch_types_in_abi():

@@ -146,6 +146,66 @@ def test_dataset_contract():
     assert torch.equal(a[0], b[0]) and a[1:] == b[1:] and a[3] == "synthetic-000003" and a[0].shape == (3, 32, 32)
 
 
+def test_undecodable_items_on_the_raw_route_are_empty_images(caplog):
+    """Reference: an image that fails to decode becomes torch.zeros(3, 224, 224) -- zeros AFTER normalisation
+    (/root/reference/src/clip/datasets/clip_dataset.py:120-125).  With the transform deferred to the GPU the item is an EMPTY uint8
+    [0, 0, 3] tensor that travels through pack_raw as a 0 x 0 descriptor (kemr_preprocess_u8_batch writes 0.0f for it): never a
+    black picture, which would normalise to (-1.79, -1.75, -1.48)."""
+    from PIL import Image
+    from knowledge_enhanced_multimodal_retrieval_amd.preprocess import ClipPreprocess, PackedRaw, pack_raw
+    rows = [{"image": Image.new("RGB", (50, 40), (9, 8, 7)), "query_text": "q", "target_text": "t", "uuid": "u0"},
+            {"image": None, "query_text": "q", "target_text": "t", "uuid": "u1"},
+            {"image": Image.new("RGB", (30, 60)), "query_text": "q", "target_text": "t", "uuid": "u2"}]
+    ds = datasets.CLIPEvalDatasetHF(rows, preprocessor=ClipPreprocess(224, defer_to_gpu=True))
+    im0, im1, im2 = ds[0][0], ds[1][0], ds[2][0]
+    assert im0.dtype == torch.uint8 and tuple(im0.shape) == (40, 50, 3)
+    assert im1.dtype == torch.uint8 and tuple(im1.shape) == (0, 0, 3)
+    packed, *_ = datasets.collate_fn_eval([ds[0], ds[1], ds[2]])
+    assert isinstance(packed, PackedRaw) and len(packed) == 3 and packed.shape == (3,)
+    assert packed.heights.tolist() == [40, 0, 60] and packed.widths.tolist() == [50, 0, 30]
+    assert packed.offsets.tolist() == [0, 6000, 6000] and packed.data.numel() == 6000 + 5400
+    moved = packed.to("cpu")
+    assert isinstance(moved, PackedRaw) and moved.heights.tolist() == [40, 0, 60]
+    only = pack_raw([im1])
+    assert len(only) == 1 and only.data.numel() == 0
+    # the host route keeps the reference's tensor
+    host = datasets.CLIPEvalDatasetHF(rows, preprocessor=ClipPreprocess(224))
+    assert torch.equal(host[1][0], torch.zeros(3, 224, 224))
+
+
+def test_library_evaluators_keep_the_reference_loader_defaults(monkeypatch):
+    """the drop-in functions default to the reference's worker counts (0: evaluator.py:101; 4:
+    evaluator_baseline.py:87, evaluator_fusion.py:42), only the CLIs opt into default_loader_workers(); a dataset or tokenize_fn that
+    cannot be pickled for the fork server gets num_workers = 0 with a warning instead of a crash; torchrun divides the count."""
+    import inspect
+    from knowledge_enhanced_multimodal_retrieval_amd import evaluators
+    sig = lambda f: inspect.signature(f).parameters["num_workers"].default
+    assert sig(evaluators.evaluate_clip_model) == 0 and sig(evaluators.encode_dataset) == 0
+    assert sig(evaluators.evaluate_clip_model_baseline) == 4 and sig(evaluators.evaluate_fusion_model) == 4
+    rows = [{"image": None, "query_text": "q", "target_text": "t", "uuid": "u"}]
+    unpicklable = datasets.CLIPEvalDatasetHF(rows, preprocessor=lambda im: torch.ones(3, 8, 8))
+    collate = datasets.CollateAndTokenize(lambda texts: torch.zeros(len(texts), 77, dtype=torch.int32))
+    monkeypatch.delenv("KEMR_LOADER_CONTEXT", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert evaluators.usable_loader_workers(unpicklable, collate, 4) == 0
+    assert evaluators.usable_loader_workers(unpicklable, collate, 0) == 0
+    ok = datasets.SyntheticRetrievalDataset(4, 8)
+    fine = datasets.CollateAndTokenize(evaluators.default_tokenize)
+    assert evaluators.usable_loader_workers(ok, fine, 4) == 4
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert evaluators.usable_loader_workers(ok, fine, 12) == 1 and evaluators.usable_loader_workers(ok, fine, 16) == 2
+    monkeypatch.setenv("KEMR_LOADER_CONTEXT", "fork")
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    assert evaluators.usable_loader_workers(unpicklable, collate, 4) == 4        # forked workers take anything, as the reference's do
+    # the loader really starts with such a dataset
+    monkeypatch.delenv("KEMR_LOADER_CONTEXT")
+    loader = evaluators.eval_loader(unpicklable, 1, 0, 4, lambda texts: torch.zeros(len(texts), 77, dtype=torch.int32), pin=False)
+    assert loader.num_workers == 0
+    images, q, t, u = next(iter(loader))
+    assert tuple(images.shape) == (1, 3, 224, 224) and u == ["u"]
+
+
 def test_sparql_dense_api_and_csr_match_reference_golden(golden_dir):
     z = np.load(os.path.join(golden_dir, "sparql_fusion.npz"))
     meta = json.loads(bytes(z["meta_json"]).decode())

@@ -147,3 +147,59 @@ def test_encode_dataset_with_gpu_preprocessing_is_identical(device):
         host = evaluators.encode_dataset(model, datasets.CLIPEvalDatasetHF(rows, preprocess), 3, 1)
         raw = evaluators.encode_dataset(model, datasets.CLIPEvalDatasetHF(rows, RawRGB()), 3, 1)
     assert torch.equal(host[0], raw[0]) and torch.equal(host[1], raw[1]) and host[3] == raw[3]
+
+
+@pytest.mark.gpu
+def test_undecodable_items_reach_the_encoder_as_the_reference_zero_tensor(device):
+    """VERDICT r3 1(i).  The reference feeds torch.zeros(3, 224, 224) -- zeros AFTER normalisation -- for an image that fails to
+    decode (/root/reference/src/clip/datasets/clip_dataset.py:120-125).  On the default (GPU-transform) route such an item is an
+    empty descriptor of kemr_preprocess_u8_batch: a split with two undecodable items gives embeddings torch.equal to the
+    host-transform run, and the embedding of those items is the fp32 oracle's embedding of a zero tensor within 1e-3 cosine.
+    Then the reference's own loop shape (DataLoader(collate_fn_eval) -> images.to(device) -> model.encode_image(images),
+    evaluator.py:96-121) on the packed batches."""
+    import warnings
+    from PIL import Image
+    import clip
+    from torch.utils.data import DataLoader
+    from knowledge_enhanced_multimodal_retrieval_amd import datasets, evaluators
+    from knowledge_enhanced_multimodal_retrieval_amd.preprocess import PackedRaw, pack_raw
+    from oracle import clip_ref
+    sizes = [(300, 400), None, (224, 224), (500, 333), None, (231, 229), (640, 480)]
+    rows = [{"image": None if hw is None else Image.fromarray(_image(hw[0], hw[1], i)), "query_text": f"vase {i} bronze",
+             "target_text": f"bronze vase number {i}", "uuid": f"u{i}"} for i, hw in enumerate(sizes)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model, preprocess = clip.load("ViT-B/32", device="cuda")
+    assert preprocess.defer_to_gpu                                    # the default route of the drop-in CLIs
+    gpu_ds = datasets.CLIPEvalDatasetHF(rows, preprocess)
+    host_ds = datasets.CLIPEvalDatasetHF(rows, ClipPreprocess(224))
+    assert tuple(gpu_ds[1][0].shape) == (0, 0, 3) and torch.equal(host_ds[1][0], torch.zeros(3, 224, 224))
+    gpu = evaluators.encode_dataset(model, gpu_ds, 3, 1)             # batches of 3: [ok, bad, ok] [ok, bad, ok] [ok]
+    host = evaluators.encode_dataset(model, host_ds, 3, 1)
+    assert torch.equal(gpu[0], host[0]) and torch.equal(gpu[1], host[1]) and gpu[3] == host[3]
+    # the kernel's own output for such an item: exact zeros, also when the whole batch is undecodable
+    pre = ClipPreprocessGPU(224, device)
+    px = pre.batch(pack_raw([gpu_ds[0][0], gpu_ds[1][0], gpu_ds[2][0]]))
+    assert torch.equal(px[1], torch.zeros_like(px[1])) and torch.equal(px[0].cpu(), host_ds[0][0]) and torch.equal(px[2].cpu(), host_ds[2][0])
+    allbad = pre.batch(pack_raw([gpu_ds[1][0], gpu_ds[4][0]]))
+    assert tuple(allbad.shape) == (2, 3, 224, 224) and float(allbad.abs().max()) == 0.0
+    assert float(pre(gpu_ds[1][0]).abs().max()) == 0.0
+    # against the oracle: the embedding of a zero tensor
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    oa = clip_ref.ARCHS["ViT-B/32"]
+    ref = clip_ref.l2_normalize(clip_ref.encode_image(sd, oa, torch.zeros(1, 3, 224, 224)))
+    for i in (1, 4):
+        cos = torch.nn.functional.cosine_similarity(gpu[0][i].double().cpu(), ref[0].double(), dim=0).item()
+        assert cos > 1 - 1e-3, (i, cos)
+    black = model.encode_image(pre.batch(pack_raw([torch.zeros(224, 224, 3, dtype=torch.uint8)])), normalize=True)
+    assert float(1 - torch.nn.functional.cosine_similarity(black[0], gpu[0][1], dim=0)) > 1e-3      # what round 3 fed instead: another embedding
+    # the reference's loop on this dataset: the packed batch moves with .to() and encode_image accepts it
+    loader = DataLoader(gpu_ds, batch_size=3, shuffle=False, num_workers=0, collate_fn=datasets.collate_fn_eval)
+    feats = []
+    for images, queries, targets, uuids in loader:
+        assert isinstance(images, PackedRaw)
+        images = images.to("cuda")
+        f = model.encode_image(images)
+        feats.append(f / f.norm(dim=-1, keepdim=True))
+    feats = torch.cat(feats)
+    assert float((1 - torch.nn.functional.cosine_similarity(feats, host[0])).max()) < 1e-5    # another batch size routes the GEMMs differently
