@@ -22,6 +22,7 @@ collective plumbing can be exercised with gloo on CPU-only machines in tests; th
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Tuple
 
 import torch
@@ -43,6 +44,24 @@ def _world(group) -> Tuple[int, int]:
     return 1, 0
 
 
+_FORCE = os.environ.get("KEMR_DIST_FORCE_COLLECTIVES", "") == "1"
+
+
+def force_collectives(on: bool = True) -> None:
+    """A world of ONE rank normally short-circuits every helper below (nothing to exchange).  With this switch on (or
+    KEMR_DIST_FORCE_COLLECTIVES=1) and a process group initialised, the collectives are issued anyway -- so that the exact calls an
+    8-GPU run makes (device-tensor all_gather_into_tensor, the device branch of require_equal_rows, async work.wait() stream
+    ordering, all_reduce, the candidate merge over [world, Q, k]) can be executed through RCCL on a one-GPU box
+    (tests/test_dist_rccl_world1.py; VERDICT r3 #2).  Results are unchanged: gathering one rank's rows is the identity."""
+    global _FORCE
+    _FORCE = bool(on)
+
+
+def _skip(world: int) -> bool:
+    """True when a helper may return without a collective: one rank and nobody asked for the collectives to run anyway."""
+    return world == 1 and not (_FORCE and dist.is_available() and dist.is_initialized())
+
+
 def _host_staged(x: torch.Tensor, group) -> bool:
     """gloo moves device tensors through the host itself only for some collectives; the rehearsal of the N > 1 path on one GPU
     (KEMR_DIST_BACKEND=gloo, bench.py) stages them explicitly.  RCCL ("nccl") never takes this branch."""
@@ -52,7 +71,7 @@ def _host_staged(x: torch.Tensor, group) -> bool:
 def all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
     """Concatenate equally shaped per-rank tensors along dim 0 (single fused all-gather)."""
     world, _ = _world(group)
-    if world == 1:
+    if _skip(world):
         return x
     x = x.contiguous()
     if _host_staged(x, group):
@@ -68,7 +87,7 @@ def all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
 def all_gather_rows_async(x: torch.Tensor, group=None):
     """As :func:`all_gather_rows`, not waited for: returns (out, work); ``work.wait()`` orders the current stream after it."""
     world, _ = _world(group)
-    if world == 1:
+    if _skip(world):
         return x, None
     x = x.contiguous()
     if _host_staged(x, group):
@@ -80,7 +99,7 @@ def all_gather_rows_async(x: torch.Tensor, group=None):
 def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
     """In-place sum over the ranks (device tensors staged through the host under gloo, see :func:`_host_staged`)."""
     world, _ = _world(group)
-    if world == 1:
+    if _skip(world):
         return x
     if _host_staged(x, group):
         xc = x.cpu()
@@ -94,7 +113,7 @@ def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
 def require_equal_rows(n_local: int, device, group=None, what: str = "query rows") -> None:
     """Refuse, on every rank, a call in which the ranks bring different row counts."""
     world, rank = _world(group)
-    if world == 1:
+    if _skip(world):
         return
     t = torch.tensor([n_local, -n_local], dtype=torch.int64)      # host tensor under gloo, device tensor under RCCL
     if dist.get_backend(group) != "gloo":
@@ -156,7 +175,7 @@ class ShardedGallery:
 
     def _exchange(self, s, i, k) -> PendingSearch:
         """Candidates of all shards -> every rank, not waited for."""
-        if self.world == 1:
+        if _skip(self.world):
             return PendingSearch(lambda a, b: (a, b), [], (s, i))
         ss, w1 = all_gather_rows_async(s.unsqueeze(0), self.group)          # [world, Q, k]
         ii, w2 = all_gather_rows_async(i.unsqueeze(0), self.group)

@@ -56,9 +56,12 @@ ARCHS: Dict[str, Dict[str, int]] = {
 }
 
 
-def random_state_dict(arch: Dict[str, int], seed: int = 0, scale: float = 1.0) -> Dict[str, torch.Tensor]:
+def random_state_dict(arch: Dict[str, int], seed: int = 0, scale: float = 1.0, outliers: bool = False) -> Dict[str, torch.Tensor]:
     """Seeded random weights with OpenAI-CLIP names/shapes (std follows the
-    upstream initialiser so activations stay O(1) through the depth)."""
+    upstream initialiser so activations stay O(1) through the depth).
+
+    ``outliers=True`` (round 4) post-processes them with what trained CLIP towers show and N(0, sigma) weights
+    do not (real weights cannot be fetched here): see :func:`add_outliers`."""
     g = torch.Generator().manual_seed(seed)
 
     def rn(*shape, std):
@@ -102,6 +105,44 @@ def random_state_dict(arch: Dict[str, int], seed: int = 0, scale: float = 1.0) -
     sd["ln_final.bias"] = rn(tw, std=0.1)
     sd["text_projection"] = rn(tw, D, std=tw ** -0.5)
     sd["logit_scale"] = torch.tensor(math.log(1 / 0.07), dtype=torch.float32)
+    if outliers:
+        add_outliers(sd, arch, seed)
+    return sd
+
+
+def add_outliers(sd: Dict[str, torch.Tensor], arch: Dict[str, int], seed: int = 0, gain_lo: float = 30.0, gain_hi: float = 100.0,
+                 per_norm: int = 4) -> Dict[str, torch.Tensor]:
+    """Heavy tails of a trained tower, in place (test infrastructure; the magnitudes follow what is published about CLIP / ViT
+    checkpoints -- residual "massive activations" two orders of magnitude above the median in a couple of channels, LayerNorm gains
+    spread over two decades, a class / start-of-text token unlike every other row):
+
+    * two MASSIVE residual channels per tower from the first LayerNorm on: ``visual.ln_pre.weight[c] *= 60`` (every token carries
+      |x_c| ~ 60 sigma, up to ~200, into all 24 blocks' statistics); text: ``token_embedding.weight[:, c] *= 60``;
+    * in EVERY block ``per_norm`` channels of ln_1 and of ln_2 with their gain scaled by U(gain_lo, gain_hi) -- the LayerNorm
+      output that feeds the QKV / fc1 GEMM then reaches ~4 sigma x 100 = 400, the neighbourhood of e4m3's +-448;
+    * a class-token-like row: ``visual.class_embedding[c'] = 1.5`` (50 sigma) and ``positional_embedding[0, c'] = 0.5`` (50 sigma on
+      the start-of-text row);
+    * one sharp head per block: the query rows of head 0 scaled by 4 (logits x 4: near one-hot softmax rows)."""
+    g = torch.Generator().manual_seed(seed * 7919 + 17)
+
+    def pick(width, k):
+        return torch.randperm(width, generator=g)[:k]
+
+    vw, tw = arch["v_width"], arch["t_width"]
+    mv, mt = pick(vw, 3), pick(tw, 3)
+    sd["visual.ln_pre.weight"][mv[:2]] *= 60.0
+    sd["token_embedding.weight"][:, mt[:2]] *= 60.0
+    sd["visual.class_embedding"][mv[2]] = 1.5
+    sd["positional_embedding"][0, mt[2]] = 0.5
+    for prefix, width, layers in (("visual.transformer", vw, arch["v_layers"]), ("transformer", tw, arch["t_layers"])):
+        for i in range(layers):
+            b = f"{prefix}.resblocks.{i}"
+            for nm in ("ln_1", "ln_2"):
+                ch = pick(width, per_norm)
+                gain = gain_lo + (gain_hi - gain_lo) * torch.rand(per_norm, generator=g)
+                sd[f"{b}.{nm}.weight"][ch] *= gain
+            sd[f"{b}.attn.in_proj_weight"][:64] *= 4.0
+            sd[f"{b}.attn.in_proj_bias"][:64] *= 4.0
     return sd
 
 

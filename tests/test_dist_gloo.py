@@ -135,3 +135,45 @@ def test_sharded_search_world2(n):
         assert np.array_equal(i, exp_i), rank
         np.testing.assert_allclose(s, exp_s, atol=1e-6)
         assert np.array_equal(ranks, exp_r)
+
+
+def _forced_worker(port, q_out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from knowledge_enhanced_multimodal_retrieval_amd import dist as kd
+    from oracle import metrics_ref
+    n, nq, d, k = 101, 16, 32, 5
+    img, q, t = metrics_ref.planted_embeddings(n, d, seed=3)
+    parts = [torch.from_numpy(img), torch.from_numpy(t)]
+    ql, gt = torch.from_numpy(q[:nq]), torch.arange(nq, dtype=torch.int32)
+    plain = kd.ShardedGallery(parts, n, ops=OracleOps)                        # no process group: everything short-circuits
+    want = plain.search([ql, ql], [0.3, 0.7], k), plain.ranks([ql, ql], gt, [0.3, 0.7], k)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    calls = {"gather": 0, "reduce": 0}
+    g0, r0 = dist.all_gather_into_tensor, dist.all_reduce
+    dist.all_gather_into_tensor = lambda *a, **kw: (calls.__setitem__("gather", calls["gather"] + 1), g0(*a, **kw))[1]
+    dist.all_reduce = lambda *a, **kw: (calls.__setitem__("reduce", calls["reduce"] + 1), r0(*a, **kw))[1]
+    unforced = kd.ShardedGallery(parts, n, ops=OracleOps).search([ql, ql], [0.3, 0.7], k)
+    assert calls == {"gather": 0, "reduce": 0}                                # world 1 without the switch: still no collective
+    kd.force_collectives(True)
+    gal = kd.ShardedGallery(parts, n, ops=OracleOps)
+    got = gal.search([ql, ql], [0.3, 0.7], k), gal.ranks([ql, ql], gt, [0.3, 0.7], k)
+    many = list(gal.search_many(([ql[i:i + 8], ql[i:i + 8]] for i in (0, 8)), [0.3, 0.7], k))
+    ok = all(torch.equal(a, b) for a, b in zip(want[0] + want[1], got[0] + got[1])) and torch.equal(unforced[1], want[0][1])
+    ok = ok and torch.equal(torch.cat([m[1] for m in many]), want[0][1])
+    kd.force_collectives(False)
+    dist.destroy_process_group()
+    q_out.put((ok, calls))
+
+
+def test_forced_collectives_at_world_size_one_change_nothing():
+    """dist.force_collectives: with ONE rank the helpers issue their collectives anyway (what tests/test_dist_rccl_world1.py runs
+    through RCCL on the GPU box) and every result equals the short-circuited call."""
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(29500 + (os.getpid() + 977) % 2000, q_out))
+    p.start()
+    ok, calls = q_out.get(timeout=120)
+    p.join(30)
+    assert ok and p.exitcode == 0
+    assert calls["gather"] >= 10 and calls["reduce"] >= 5, calls

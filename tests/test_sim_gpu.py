@@ -188,8 +188,46 @@ def test_rank_dense_matches_oracle(device):
     assert np.array_equal(ranks.cpu().numpy(), metrics_ref.ranks_by_sort(sq))
 
 
+def _fp64_slice_check(q_parts, g_parts, weights, off, gt, top_s, top_i, ahead, k, eps, n_rows=256):
+    """An INDEPENDENT reference at BASELINE size: fp64 CPU scores of `n_rows` evenly spaced queries against the
+    WHOLE gallery -- numpy's matmul, none of this build's kernels -- ranked as the reference does (metrics.py:34-41, 62-68: descending
+    score; ties, which numpy's argsort leaves undefined, by lower index).  eps = the documented score error of the panel precision
+    (2e-3 bf16 panels, 2e-6 fp32x3).  Checked per query: (a) every reported score is the fp64 score of its id within eps; (b) the
+    top-k SET equals the fp64 top-k set wherever the fp64 k / k+1 margin exceeds 2 eps, and otherwise every reported id scores
+    within 2 eps of the fp64 k-th score or above it; (c) the rank count lies between the counts of the candidates clearly ahead of
+    and possibly ahead of the ground truth (fp64 score > s_gt + 2 eps / >= s_gt - 2 eps)."""
+    nq = top_i.shape[0]
+    rows = np.unique(np.linspace(0, nq - 1, min(n_rows, nq)).round().astype(np.int64))
+    S = np.zeros((len(rows), g_parts[0].shape[0]), dtype=np.float64)
+    for qp_, gp_, w in zip(q_parts, g_parts, weights):
+        S += w * (qp_[rows].double().cpu().numpy() @ gp_.double().cpu().numpy().T)
+    ti, ts = top_i.cpu().numpy()[rows].astype(np.int64) - off, top_s.cpu().numpy()[rows].astype(np.float64)
+    gt_ = gt.cpu().numpy()[rows].astype(np.int64) - off
+    ah = ahead.cpu().numpy()[rows].astype(np.int64)
+    ids = np.arange(S.shape[1])
+    stats = {"rows": len(rows), "identical_sets": 0, "clear_margin": 0, "max_score_err": 0.0}
+    for r in range(len(rows)):
+        assert (ti[r] >= 0).all() and (ti[r] < S.shape[1]).all()
+        err = np.abs(S[r, ti[r]] - ts[r]).max()
+        stats["max_score_err"] = max(stats["max_score_err"], float(err))
+        assert err < eps, (r, err)                                                           # (a)
+        order = np.lexsort((ids, -S[r]))[:k + 1]
+        want, kth, nxt = set(order[:k].tolist()), S[r, order[k - 1]], S[r, order[k]]
+        if kth - nxt > 2 * eps:                                                              # (b)
+            stats["clear_margin"] += 1
+            assert set(ti[r].tolist()) == want, (r, kth - nxt)
+        assert (S[r, ti[r]] >= kth - 2 * eps).all(), r
+        stats["identical_sets"] += int(set(ti[r].tolist()) == want)
+        sg = S[r, gt_[r]]                                                                     # (c)
+        lo = int((S[r] > sg + 2 * eps).sum())
+        hi = int((S[r] >= sg - 2 * eps).sum()) - 1
+        assert lo <= ah[r] <= hi, (r, lo, int(ah[r]), hi)
+    return stats
+
+
 def test_full_gallery_properties(device):
-    """BASELINE sizes (43k gallery, D=768): no oracle at this size; check size-independent properties."""
+    """BASELINE sizes (43k gallery, D=768): size-independent properties, and since round 4 an independent fp64 CPU reference for
+    256 of the queries against the whole gallery (_fp64_slice_check)."""
     n, d, nq, k = 43000, 768, 1024, 10
     g = torch.Generator(device="cpu").manual_seed(0)
     gal = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=-1).to(device)
@@ -209,6 +247,8 @@ def test_full_gallery_properties(device):
     assert torch.equal(in_list, ahead < k)
     assert torch.equal(top_i[:, 0] == gt, ahead == 0)
     assert float((ahead == 0).float().mean()) > 0.9             # the planted signal is strong
+    st = _fp64_slice_check([qry], [gal], [1.0], 0, gt, top_s, top_i, ahead, k, eps=2e-3)
+    assert st["rows"] == 256 and st["clear_margin"] >= 200, st   # the planted margin is far above the bf16 error for most queries
     # (3) 8-way sharding with global ids + merge reproduces the single-gallery answer (config 4's data path)
     per = (n + 7) // 8
     ps, pi = [], []
@@ -323,6 +363,9 @@ def test_topk_by_candidate_lists_is_the_kernel_path_bit_for_bit(device, nq, ng, 
             pi.append(i_)
         ms, mi = engine.topk_merge(torch.stack(ps, 1), torch.stack(pi, 1), k)
         assert torch.equal(ms, out[1][0]) and torch.equal(mi, out[1][1]) and torch.equal(ahead2, out[1][2])
+    if ng >= 43000:       # BASELINE size: beyond the dense check below -- an independent fp64 CPU reference for 256 of the queries
+        st = _fp64_slice_check([qry], [gal], [1.0], off, gtg, out[1][0], out[1][1], out[1][2], k, eps=2e-3 if terms == 1 else 2e-6)
+        assert st["rows"] == 256, st
     if nq * ng <= 2e7:
         S = engine.scores_dense(qp, gp)
         order = torch.sort(S, dim=1, descending=True, stable=True)
@@ -386,6 +429,9 @@ def test_full_gallery_fused_two_part_properties(device, terms):
     # linearity against fp64
     want = wi * (qry.double() * img[:nq].double()).sum(-1) + wt * (qry.double() * tgt[:nq].double()).sum(-1)
     assert float((sgt.double() - want).abs().max()) < (3e-3 if terms == 1 else 2e-6)
+    # an independent fp64 CPU reference for 256 of the queries against all 43 000 fused scores (metrics.py:145-148)
+    st = _fp64_slice_check([qry, qry], [img, tgt], [wi, wt], 0, gt, top_s, top_i, ahead, k, eps=2e-3 if terms == 1 else 2e-6)
+    assert st["rows"] == 256, st
     # 8-way sharding + merge = the single-gallery answer
     per = (n + 7) // 8
     ps, pi = [], []
