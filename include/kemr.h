@@ -56,11 +56,14 @@ typedef enum kemr_dtype { KEMR_F32 = 0, KEMR_BF16 = 1, KEMR_I32 = 2, KEMR_FP8 = 
  *                       of HBM traffic per residual element and LayerNorm, and 16 instead of 18 workspace bytes.
  *                       For calls of more than 512 token rows the residual add runs inside the out-proj / fc2 GEMM epilogues
  *                       unless the environment holds KEMR_RESADD=0 (x is then rounded once per layer instead of twice, -3.7 %).
- * KEMR_PREC_FP8:        BASELINE config 5.  The QKV GEMMs (24 % of the FLOPs) run on fp8 e4m3 operands with the block-scaled
- *                       MFMA (K = 128 per instruction, twice the bf16 rate): ln_1 writes its output as e4m3 (unit scale,
- *                       saturating), the weights are quantised per output channel at finalize, the scale is applied to the
- *                       fp32 accumulators.  Everything else as KEMR_PREC_BF16.  Recall@10 stays within 0.2 points of bf16
- *                       (tests/test_encoder_gpu.py).  Widths must be multiples of 128 (>= 256).
+ * KEMR_PREC_FP8:        BASELINE config 5.  The QKV GEMMs of the VISION tower (22 % of a gallery item's FLOPs) run on fp8 e4m3
+ *                       operands with the block-scaled MFMA (K = 128 per instruction, twice the bf16 rate): ln_1 writes its
+ *                       output as e4m3 -- its gain moved out of the values by per-channel power-of-two scales that finalize folds
+ *                       into gamma / beta and into the weight columns, so that a trained tower's gains of 30-100 do not saturate
+ *                       at +-448 (round 4) --, the weights are quantised per output channel at finalize, the scale is applied
+ *                       to the fp32 accumulators.  The text tower (one pooled row behind a causal softmax: e4m3 q / k / v cost
+ *                       it 1 - cos 1.4e-3 .. 5e-3, over the path's 1e-3 bar) and everything else stay as KEMR_PREC_BF16.
+ *                       Recall@10 stays within 0.2 points of bf16 (tests/test_encoder_gpu.py).  Vision width: multiple of 128.
  * KEMR_PREC_FP8_MLP:    the fc1 GEMMs as well (56 % of the FLOPs in fp8, +25 % encode throughput); on the synthetic
  *                       near-duplicate retrieval test this costs about one point of Recall@10 where bf16 is below 90 %
  *                       (the MLP update goes straight into the residual stream, the QKV error is averaged by the softmax),

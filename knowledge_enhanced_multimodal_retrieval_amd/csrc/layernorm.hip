@@ -43,7 +43,9 @@ __device__ __forceinline__ void store_row4(bf16_t* r, int i, float4 v, int) {
     ((uint2*)r)[i] = pk;
 }
 
-struct fp8_t { uint8_t v; };          // output tag: OCP e4m3 bytes (the A operand of the fp8 GEMMs), unit scale, saturating
+struct fp8_t { uint8_t v; };          // output tag: OCP e4m3 bytes (the A operand of the fp8 GEMMs), saturating.  The per-channel scale of the
+                                      // operand lives in gamma / beta (api.hip finalize divides them by 2^ceil(log2 max(|gamma|, |beta|))
+                                      // and multiplies the weight columns): the values written here are |z * gamma' + beta'| <= ~45
 __device__ __forceinline__ void store_row4(fp8_t* r, int i, float4 v, int) {
     const float lim = 448.f;
     int pk = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v.x, -lim, lim), __builtin_amdgcn_fmed3f(v.y, -lim, lim), 0, false);

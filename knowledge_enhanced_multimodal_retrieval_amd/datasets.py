@@ -109,6 +109,39 @@ class SyntheticHFSplit:
         return {"image": Image.fromarray(image.numpy()), "query_text": query, "target_text": target, "uuid": uid}
 
 
+class SyntheticJPEGSplit:
+    """As :class:`SyntheticHFSplit`, with the image stored the way the HuggingFace ``datasets`` Image feature stores it -- ENCODED
+    bytes (JPEG here, as photographs are) that are decoded with Pillow when the row is read, i.e. inside the loader worker
+    (reference: ``CLIPEvalDatasetHF.__getitem__`` receives the decoded PIL image from ``datasets``, clip_dataset.py:110-113).  The
+    bytes are encoded in memory at construction (no files, no network): ``distinct`` different pictures over the eight camera-like
+    sizes, row idx reads picture idx % distinct -- what a row costs is its decode, which does not care that pictures repeat."""
+
+    def __init__(self, n: int, seed: int = 42, distinct: int = 256, quality: int = 90):
+        import io
+        from PIL import Image
+        self.n = n
+        self._raw = SyntheticRawImageDataset(max(n, 1), seed)
+        self._jpeg = []
+        for i in range(min(distinct, max(n, 1))):
+            buf = io.BytesIO()
+            Image.fromarray(self._raw[i][0].numpy()).save(buf, format="JPEG", quality=quality)
+            self._jpeg.append(buf.getvalue())
+
+    def __len__(self):
+        return self.n
+
+    def mean_jpeg_bytes(self) -> float:
+        return sum(len(b) for b in self._jpeg) / max(len(self._jpeg), 1)
+
+    def __getitem__(self, idx):
+        import io
+        from PIL import Image
+        _, query, target, uid = self._raw._texts[idx]
+        image = Image.open(io.BytesIO(self._jpeg[idx % len(self._jpeg)]))
+        image.load()                                   # decode now (datasets' Image feature does the same on access)
+        return {"image": image, "query_text": query, "target_text": target, "uuid": uid}
+
+
 class SyntheticRawImageDataset(Dataset):
     """The same texts as :class:`SyntheticRetrievalDataset`, with the image as a camera-like uint8 ``[H, W, 3]`` array of a
     seeded size (the reference's dataset returns PIL images of whatever size the file has, clip_dataset.py:110-125): the

@@ -110,19 +110,30 @@ def random_state_dict(arch: Dict[str, int], seed: int = 0, scale: float = 1.0, o
     return sd
 
 
-def add_outliers(sd: Dict[str, torch.Tensor], arch: Dict[str, int], seed: int = 0, gain_lo: float = 30.0, gain_hi: float = 100.0,
-                 per_norm: int = 4) -> Dict[str, torch.Tensor]:
-    """Heavy tails of a trained tower, in place (test infrastructure; the magnitudes follow what is published about CLIP / ViT
-    checkpoints -- residual "massive activations" two orders of magnitude above the median in a couple of channels, LayerNorm gains
-    spread over two decades, a class / start-of-text token unlike every other row):
+def add_outliers(sd: Dict[str, torch.Tensor], arch: Dict[str, int], seed: int = 0, gain_lo: float = 3.0, gain_hi: float = 10.0,
+                 per_norm: int = 4, massive: float = 60.0, cls_row: bool = True, sharp: float = 4.0,
+                 migrate_lo: float = 30.0, migrate_hi: float = 100.0) -> Dict[str, torch.Tensor]:
+    """Heavy tails of a trained tower, in place (test infrastructure; real weights cannot be fetched here, the magnitudes follow what
+    is published about CLIP / ViT checkpoints -- residual "massive activations" two orders of magnitude above the median in a couple
+    of channels, LayerNorm gains spread over two decades, a class / start-of-text row unlike every other row, sharp heads):
 
-    * two MASSIVE residual channels per tower from the first LayerNorm on: ``visual.ln_pre.weight[c] *= 60`` (every token carries
-      |x_c| ~ 60 sigma, up to ~200, into all 24 blocks' statistics); text: ``token_embedding.weight[:, c] *= 60``;
-    * in EVERY block ``per_norm`` channels of ln_1 and of ln_2 with their gain scaled by U(gain_lo, gain_hi) -- the LayerNorm
-      output that feeds the QKV / fc1 GEMM then reaches ~4 sigma x 100 = 400, the neighbourhood of e4m3's +-448;
-    * a class-token-like row: ``visual.class_embedding[c'] = 1.5`` (50 sigma) and ``positional_embedding[0, c'] = 0.5`` (50 sigma on
-      the start-of-text row);
-    * one sharp head per block: the query rows of head 0 scaled by 4 (logits x 4: near one-hot softmax rows)."""
+    * two MASSIVE residual channels per tower from the first LayerNorm on: ``visual.ln_pre.weight[c] *= massive`` (every token carries
+      |x_c| ~ 60 sigma, up to ~200, into all blocks' statistics); text: ``token_embedding.weight[:, c] *= massive``;
+    * a class-token-like row: ``visual.class_embedding[c'] = 1.5`` (50 sigma), ``positional_embedding[0, c'] = 0.5`` (50 sigma on the
+      start-of-text row);
+    * one sharp head per block: the query rows of head 0 scaled by ``sharp`` (logits x 4: near one-hot softmax rows);
+    * in EVERY block ``per_norm`` channels of ln_1 and of ln_2 with their gain scaled by U(gain_lo, gain_hi) = 3 .. 10, NOT
+      compensated: the function changes, those channels dominate the QKV / fc1 inputs;
+    * in EVERY block ``per_norm`` further channels of ln_1 and ln_2 with gain AND bias scaled by g ~ U(migrate_lo, migrate_hi) =
+      30 .. 100 and the consuming weight columns (in_proj_weight / c_fc.weight [:, c]) divided by g: the function is unchanged in real
+      arithmetic, but the LayerNorm OUTPUT -- the A operand of the QKV / fc1 GEMM -- reaches 4 sigma x 100 = 400 in those channels,
+      the neighbourhood of e4m3's +-448.  This is how large gains occur in trained towers (gain and weight column trade places
+      freely under training); floating-point bf16 does not care, a unit-scale saturating e4m3 store does.
+
+    Measured with :func:`encode_image` / :func:`encode_text` ``(bf16_operands=True)`` (an emulation of bf16 operands on the CPU, no
+    kernel involved): UNcompensated gains of 30 .. 100 put the attention logits at ~1e4 -- the towers become chaotic functions and
+    ANY bf16-operand arithmetic leaves the fp32 oracle by 1 - cos 3e-2 .. 1e-1 (ViT-B/32; gains of 10 .. 30: 4e-5 / 4e-4; 3 .. 10:
+    4e-6 / 3e-5).  That regime says nothing about an implementation, so the uncompensated gains stop at 10."""
     g = torch.Generator().manual_seed(seed * 7919 + 17)
 
     def pick(width, k):
@@ -130,46 +141,78 @@ def add_outliers(sd: Dict[str, torch.Tensor], arch: Dict[str, int], seed: int = 
 
     vw, tw = arch["v_width"], arch["t_width"]
     mv, mt = pick(vw, 3), pick(tw, 3)
-    sd["visual.ln_pre.weight"][mv[:2]] *= 60.0
-    sd["token_embedding.weight"][:, mt[:2]] *= 60.0
-    sd["visual.class_embedding"][mv[2]] = 1.5
-    sd["positional_embedding"][0, mt[2]] = 0.5
+    if massive:
+        sd["visual.ln_pre.weight"][mv[:2]] *= massive
+        sd["token_embedding.weight"][:, mt[:2]] *= massive
+    if cls_row:
+        sd["visual.class_embedding"][mv[2]] = 1.5
+        sd["positional_embedding"][0, mt[2]] = 0.5
     for prefix, width, layers in (("visual.transformer", vw, arch["v_layers"]), ("transformer", tw, arch["t_layers"])):
         for i in range(layers):
             b = f"{prefix}.resblocks.{i}"
-            for nm in ("ln_1", "ln_2"):
-                ch = pick(width, per_norm)
+            for nm, consumer in (("ln_1", f"{b}.attn.in_proj_weight"), ("ln_2", f"{b}.mlp.c_fc.weight")):
+                ch = pick(width, 2 * per_norm)
                 gain = gain_lo + (gain_hi - gain_lo) * torch.rand(per_norm, generator=g)
-                sd[f"{b}.{nm}.weight"][ch] *= gain
-            sd[f"{b}.attn.in_proj_weight"][:64] *= 4.0
-            sd[f"{b}.attn.in_proj_bias"][:64] *= 4.0
+                mig = migrate_lo + (migrate_hi - migrate_lo) * torch.rand(per_norm, generator=g)
+                if gain_hi > 0:
+                    sd[f"{b}.{nm}.weight"][ch[:per_norm]] *= gain
+                if migrate_hi > 0:
+                    sd[f"{b}.{nm}.weight"][ch[per_norm:]] *= mig
+                    sd[f"{b}.{nm}.bias"][ch[per_norm:]] *= mig
+                    sd[consumer][:, ch[per_norm:]] /= mig
+            if sharp:
+                sd[f"{b}.attn.in_proj_weight"][:64] *= sharp
+                sd[f"{b}.attn.in_proj_bias"][:64] *= sharp
     return sd
 
 
-def _block(x: torch.Tensor, sd, prefix: str, heads: int, causal: bool) -> torch.Tensor:
-    """One pre-LN residual attention block on x [B, T, W] (fp32)."""
+def _bf16(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _block(x: torch.Tensor, sd, prefix: str, heads: int, causal: bool, bf16_operands: bool = False) -> torch.Tensor:
+    """One pre-LN residual attention block on x [B, T, W] (fp32).
+
+    ``bf16_operands`` (a DIAGNOSTIC of the precision class, not the oracle): every GEMM / attention operand and every stored
+    intermediate is rounded to bf16 where the build's default precision holds it in bf16 (LayerNorm outputs, weights, q | k | v, the
+    softmax probabilities, the attention output, the out-proj / fc2 updates, the MLP hidden), fp32 accumulation and an fp32
+    residual stream -- what ANY bf16-operand implementation computes, up to summation order.  tools/outlier_stress.py uses it to
+    tell the cost of bf16 operands on heavy-tailed weights from a defect of the kernels."""
+    r = _bf16 if bf16_operands else (lambda t: t)
     B, T, W = x.shape
     hd = W // heads
-    h = F.layer_norm(x, (W,), sd[f"{prefix}.ln_1.weight"], sd[f"{prefix}.ln_1.bias"], 1e-5)
-    qkv = h @ sd[f"{prefix}.attn.in_proj_weight"].T + sd[f"{prefix}.attn.in_proj_bias"]
-    q, k, v = qkv.split(W, dim=-1)
+    h = r(F.layer_norm(x, (W,), sd[f"{prefix}.ln_1.weight"], sd[f"{prefix}.ln_1.bias"], 1e-5))
+    wq, bq = sd[f"{prefix}.attn.in_proj_weight"], sd[f"{prefix}.attn.in_proj_bias"]
+    if bf16_operands:                              # the build folds 1 / sqrt(64) into W_q / b_q (exact) and stores q | k | v as bf16
+        scale = torch.ones(3 * W)
+        scale[:W] = hd ** -0.5
+        qkv = r(h @ r(wq * scale[:, None]).T + bq * scale)
+        q, k, v = qkv.split(W, dim=-1)
+    else:
+        qkv = h @ wq.T + bq
+        q, k, v = qkv.split(W, dim=-1)
+        q = q * (hd ** -0.5)
     q = q.view(B, T, heads, hd).transpose(1, 2)
     k = k.view(B, T, heads, hd).transpose(1, 2)
     v = v.view(B, T, heads, hd).transpose(1, 2)
-    s = (q * (hd ** -0.5)) @ k.transpose(-1, -2)
+    s = q @ k.transpose(-1, -2)
     if causal:
         s = s + torch.full((T, T), float("-inf")).triu_(1)
-    a = torch.softmax(s, dim=-1) @ v
-    a = a.transpose(1, 2).reshape(B, T, W)
-    x = x + a @ sd[f"{prefix}.attn.out_proj.weight"].T + sd[f"{prefix}.attn.out_proj.bias"]
-    h = F.layer_norm(x, (W,), sd[f"{prefix}.ln_2.weight"], sd[f"{prefix}.ln_2.bias"], 1e-5)
-    h = h @ sd[f"{prefix}.mlp.c_fc.weight"].T + sd[f"{prefix}.mlp.c_fc.bias"]
-    h = h * torch.sigmoid(1.702 * h)
-    return x + h @ sd[f"{prefix}.mlp.c_proj.weight"].T + sd[f"{prefix}.mlp.c_proj.bias"]
+    if bf16_operands:                              # row sum of the fp32 exponentials, P rounded to bf16 for the PV product
+        p = torch.exp(s - s.amax(dim=-1, keepdim=True))
+        a = (r(p) @ v) / p.sum(dim=-1, keepdim=True)
+    else:
+        a = torch.softmax(s, dim=-1) @ v
+    a = r(a.transpose(1, 2).reshape(B, T, W))
+    x = x + r(a @ r(sd[f"{prefix}.attn.out_proj.weight"]).T + sd[f"{prefix}.attn.out_proj.bias"])
+    h = r(F.layer_norm(x, (W,), sd[f"{prefix}.ln_2.weight"], sd[f"{prefix}.ln_2.bias"], 1e-5))
+    h = h @ r(sd[f"{prefix}.mlp.c_fc.weight"]).T + sd[f"{prefix}.mlp.c_fc.bias"]
+    h = r(h * torch.sigmoid(1.702 * h))
+    return x + r(h @ r(sd[f"{prefix}.mlp.c_proj.weight"]).T + sd[f"{prefix}.mlp.c_proj.bias"])
 
 
 @torch.no_grad()
-def encode_image(sd, arch, pixels: torch.Tensor, return_hidden: bool = False) -> torch.Tensor:
+def encode_image(sd, arch, pixels: torch.Tensor, return_hidden: bool = False, bf16_operands: bool = False) -> torch.Tensor:
     """pixels [B,3,S,S] fp32 (already mean/std normalised) -> [B, embed_dim] fp32 (un-normalised)."""
     sd = {k: v.float() for k, v in sd.items() if k.startswith("visual.")}
     vw, p = arch["v_width"], arch["patch"]
@@ -179,7 +222,7 @@ def encode_image(sd, arch, pixels: torch.Tensor, return_hidden: bool = False) ->
     x = torch.cat([cls, x], dim=1) + sd["visual.positional_embedding"]
     x = F.layer_norm(x, (vw,), sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"], 1e-5)
     for i in range(arch["v_layers"]):
-        x = _block(x, sd, f"visual.transformer.resblocks.{i}", vw // 64, causal=False)
+        x = _block(x, sd, f"visual.transformer.resblocks.{i}", vw // 64, causal=False, bf16_operands=bf16_operands)
     if return_hidden:
         return x
     x = F.layer_norm(x[:, 0, :], (vw,), sd["visual.ln_post.weight"], sd["visual.ln_post.bias"], 1e-5)
@@ -187,14 +230,14 @@ def encode_image(sd, arch, pixels: torch.Tensor, return_hidden: bool = False) ->
 
 
 @torch.no_grad()
-def encode_text(sd, arch, ids: torch.Tensor, return_hidden: bool = False) -> torch.Tensor:
+def encode_text(sd, arch, ids: torch.Tensor, return_hidden: bool = False, bf16_operands: bool = False) -> torch.Tensor:
     """ids [B, ctx] int -> [B, embed_dim] fp32 (un-normalised); pooled at argmax(ids) (EOT = highest id)."""
     sd = {k: v.float() for k, v in sd.items() if not k.startswith("visual.")}
     tw = arch["t_width"]
     ids = ids.long()
     x = sd["token_embedding.weight"][ids] + sd["positional_embedding"][: ids.shape[1]]
     for i in range(arch["t_layers"]):
-        x = _block(x, sd, f"transformer.resblocks.{i}", tw // 64, causal=True)
+        x = _block(x, sd, f"transformer.resblocks.{i}", tw // 64, causal=True, bf16_operands=bf16_operands)
     if return_hidden:
         return x
     x = F.layer_norm(x, (tw,), sd["ln_final.weight"], sd["ln_final.bias"], 1e-5)

@@ -127,6 +127,36 @@ def test_full_size_models_match_oracle(device, name, nimg, ntxt, precision):
     assert float((1 - ci).max()) < COS_TOL and float((1 - ct).max()) < COS_TOL
 
 
+@pytest.mark.parametrize("precision", ["bf16", "bf16-x24", "bf16-res16", "fp8", "fp8-x24"])
+@pytest.mark.parametrize("name,nimg,ntxt", [("ViT-B/32", 4, 6), ("ViT-L/14", 3, 4)])
+def test_heavy_tailed_weights_match_oracle(device, name, nimg, ntxt, precision):
+    """every other parity test runs on N(0, sigma) weights.  oracle.clip_ref.add_outliers gives the towers what
+    trained CLIP checkpoints are known for -- two massive residual channels (x 60), LayerNorm gains of 3 .. 10 (uncompensated) and
+    of 30 .. 100 (migrated out of the consuming weight columns: the LayerNorm OUTPUT reaches ~400 there, next to e4m3's +-448), a
+    class-token-like row, a sharp head per block -- and the path's 1e-3 cosine bar must hold for the default, for the 24-bit
+    residual stream and for the fp8 modes (whose A operand carries per-channel scales since round 4; with round 3's unit-scale
+    saturating store the same weights gave 1 - cos 9e-2 .. 3e-1).  Measured (tools/outlier_stress.py): bf16 3e-6 / 4e-5 (image /
+    text), fp8 1e-4 / as bf16.  What these weights do NOT contain: uncompensated gains of 30 .. 100, which put the attention
+    logits at ~1e4 and make the towers chaotic -- there a CPU emulation of bf16 operands (clip_ref ... bf16_operands=True, no
+    kernel involved) leaves the fp32 oracle by 3e-2 .. 1e-1 just the same: a statement about the precision class, not testable as
+    parity."""
+    arch = ARCHS[name]
+    oa = clip_ref.ARCHS[name]
+    sd = clip_ref.random_state_dict(oa, seed=0, outliers=True)
+    assert max(float(v.abs().max()) for k, v in sd.items() if k.endswith("ln_1.weight")) > 25.0
+    eng = engine.ClipEngine(arch, device, precision=precision)
+    eng.load_state_dict(sd)
+    g = torch.Generator().manual_seed(1234)
+    px = torch.randn(nimg, 3, 224, 224, generator=g)
+    ids = clip_ref.synthetic_ids(oa, ntxt)
+    ref_i, ref_t = clip_ref.encode_image(sd, oa, px), clip_ref.encode_text(sd, oa, ids)
+    got_i, got_t = eng.encode_image(px.to(device)).cpu(), eng.encode_text(ids.to(device)).cpu()
+    assert bool(torch.isfinite(got_i).all()) and bool(torch.isfinite(got_t).all())
+    ci, ct = _cos(got_i, ref_i), _cos(got_t, ref_t)
+    print(f"{name} {precision} heavy-tailed: image 1-cos max {float((1 - ci).max()):.2e}, text 1-cos max {float((1 - ct).max()):.2e}")
+    assert float((1 - ci).max()) < COS_TOL and float((1 - ct).max()) < COS_TOL
+
+
 def test_bench_shape_batch_matches_oracle(device):
     """The shape bench.py runs: ViT-L/14, 255 items per encoder call = 65 535 token rows = 256 row tiles of the
     persistent GEMM with the ragged last row, the long-K fc2 path and 12-16 tiles per workgroup; texts 255 x 77 rows.  Nine
@@ -142,7 +172,9 @@ def test_bench_shape_batch_matches_oracle(device):
     ref_i = clip_ref.encode_image(sd, oa, px[pick])
     ref_t = clip_ref.encode_text(sd, oa, ids[pick])
     pxd, idd = px.to(device), ids.to(device)
-    for precision, tol in (("bf16", COS_TOL), ("bf16-res16", COS_TOL), ("fp8", 5e-3), ("fp8-res16", 5e-3)):
+    # (round 4: fp8 operands are confined to the vision tower, whose embedding averages 257 rows -- the fp8 modes are held to the
+    #  path's own 1e-3 bar like every other precision; round 3 allowed them 5e-3 because of the text tower's 1.6e-3)
+    for precision, tol in (("bf16", COS_TOL), ("bf16-res16", COS_TOL), ("fp8", COS_TOL), ("fp8-res16", COS_TOL)):
         eng = engine.ClipEngine(ARCHS[name], device, precision=precision)
         eng.load_state_dict(sd)
         got_i = eng.encode_image(pxd).cpu()
@@ -157,11 +189,16 @@ def test_bench_shape_batch_matches_oracle(device):
         del eng
 
 
-@pytest.mark.parametrize("precision,tol", [("fp8", 5e-3), ("fp8-res16", 5e-3), ("fp8-mlp", 2e-2)])
-@pytest.mark.parametrize("name,nimg,ntxt", [("tiny", 9, 11), ("ViT-L/14", 2, 3)])
+@pytest.mark.parametrize("precision,tol", [("fp8", COS_TOL), ("fp8-res16", COS_TOL), ("fp8-mlp", COS_TOL)])
+@pytest.mark.parametrize("name,nimg,ntxt", [("tiny", 9, 11), ("ViT-B/32", 3, 4), ("ViT-L/14", 2, 3)])
 def test_fp8_encoders_match_oracle(device, name, nimg, ntxt, precision, tol):
-    """BASELINE config 5: QKV (and, "fp8-mlp", fc1) on fp8 e4m3 operands.  The cosine bar of the bf16 path (1e-3) does
-    not apply to 3-bit mantissas; what config 5 asks for is Recall@10 within 0.2 % of bf16 (next test).  Here: bounded."""
+    """BASELINE config 5: the vision tower's QKV (and, "fp8-mlp", fc1) on fp8 e4m3 operands; the text tower stays on bf16 operands
+    (round 4: e4m3 q / k / v cost its one pooled row 1 - cos 1.4e-3 .. 5e-3, over north_star's 1e-3, for 1 % of throughput).  At
+    the full-size models every fp8 mode is inside the path's 1e-3 cosine bar (round 3 allowed 5e-3); the 2-layer, 17-token "tiny"
+    image tower has nothing to average the e4m3 error over and keeps a 5e-3 bound.  What config 5 itself asks for is Recall@10
+    within 0.2 points of bf16 (next test)."""
+    if name == "tiny":
+        tol = 5e-3 if precision != "fp8-mlp" else 2e-2
     arch, sd, eng = _engine(name, device, precision=precision)
     oa = clip_ref.ARCHS[name]
     g = torch.Generator().manual_seed(1234)

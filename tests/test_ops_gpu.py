@@ -444,7 +444,7 @@ def test_attention_257_both_kernels_and_exact_structure(device, batch, width):
     qkv_bf = qkv.to(torch.bfloat16)
     ref = _attention_ref(qkv_bf, batch, t, width, False)
     outs = {}
-    variants = (0, 1, 2, 3, 4) if debug.ab_variants() else (0,)
+    variants = (0, 1, 2, 3, 4, 5) if debug.ab_variants() else (0,)
     for v in variants:
         with debug.override(attn_v=v):
             outs[v] = engine.op_attention(qkv_bf.to(device), batch, t, width, False).float().cpu()

@@ -192,10 +192,11 @@ def _fp64_slice_check(q_parts, g_parts, weights, off, gt, top_s, top_i, ahead, k
     """An INDEPENDENT reference at BASELINE size: fp64 CPU scores of `n_rows` evenly spaced queries against the
     WHOLE gallery -- numpy's matmul, none of this build's kernels -- ranked as the reference does (metrics.py:34-41, 62-68: descending
     score; ties, which numpy's argsort leaves undefined, by lower index).  eps = the documented score error of the panel precision
-    (2e-3 bf16 panels, 2e-6 fp32x3).  Checked per query: (a) every reported score is the fp64 score of its id within eps; (b) the
-    top-k SET equals the fp64 top-k set wherever the fp64 k / k+1 margin exceeds 2 eps, and otherwise every reported id scores
-    within 2 eps of the fp64 k-th score or above it; (c) the rank count lies between the counts of the candidates clearly ahead of
-    and possibly ahead of the ground truth (fp64 score > s_gt + 2 eps / >= s_gt - 2 eps)."""
+    (2e-3 bf16 panels, 2e-6 fp32x3).  Checked per query: (a) every reported score is the fp64 score of its id within eps -- the
+    largest deviation E is MEASURED and the rules below use it (random unit vectors leave a 10 / 11 margin of ~1e-3: a rule at the
+    documented bound would bind almost nowhere); (b) the top-k SET equals the fp64 top-k set wherever the fp64 k / k+1 margin exceeds
+    2 E, and every reported id scores within 2 E of the fp64 k-th score or above it; (c) the rank count lies between the counts of
+    the candidates clearly ahead of and possibly ahead of the ground truth (fp64 score > s_gt + 2 E / >= s_gt - 2 E)."""
     nq = top_i.shape[0]
     rows = np.unique(np.linspace(0, nq - 1, min(n_rows, nq)).round().astype(np.int64))
     S = np.zeros((len(rows), g_parts[0].shape[0]), dtype=np.float64)
@@ -206,11 +207,11 @@ def _fp64_slice_check(q_parts, g_parts, weights, off, gt, top_s, top_i, ahead, k
     ah = ahead.cpu().numpy()[rows].astype(np.int64)
     ids = np.arange(S.shape[1])
     stats = {"rows": len(rows), "identical_sets": 0, "clear_margin": 0, "max_score_err": 0.0}
+    assert (ti >= 0).all() and (ti < S.shape[1]).all()
+    stats["max_score_err"] = float(np.abs(np.take_along_axis(S, ti, axis=1) - ts).max())
+    assert stats["max_score_err"] < eps, stats                                               # (a)
+    eps = stats["max_score_err"] + 1e-7                                                      # E, measured
     for r in range(len(rows)):
-        assert (ti[r] >= 0).all() and (ti[r] < S.shape[1]).all()
-        err = np.abs(S[r, ti[r]] - ts[r]).max()
-        stats["max_score_err"] = max(stats["max_score_err"], float(err))
-        assert err < eps, (r, err)                                                           # (a)
         order = np.lexsort((ids, -S[r]))[:k + 1]
         want, kth, nxt = set(order[:k].tolist()), S[r, order[k - 1]], S[r, order[k]]
         if kth - nxt > 2 * eps:                                                              # (b)
@@ -248,7 +249,8 @@ def test_full_gallery_properties(device):
     assert torch.equal(top_i[:, 0] == gt, ahead == 0)
     assert float((ahead == 0).float().mean()) > 0.9             # the planted signal is strong
     st = _fp64_slice_check([qry], [gal], [1.0], 0, gt, top_s, top_i, ahead, k, eps=2e-3)
-    assert st["rows"] == 256 and st["clear_margin"] >= 200, st   # the planted margin is far above the bf16 error for most queries
+    print("fp64 slice at 43k:", st)
+    assert st["rows"] == 256 and st["clear_margin"] >= 20 and st["identical_sets"] >= 200, st
     # (3) 8-way sharding with global ids + merge reproduces the single-gallery answer (config 4's data path)
     per = (n + 7) // 8
     ps, pi = [], []
