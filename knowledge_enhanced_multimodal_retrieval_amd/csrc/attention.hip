@@ -265,226 +265,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
     }
 }
 
-// ---- T = 257, persistent: the NEXT item's K / V prefetched into registers while this one's tiles run (round 4) -------------------------
-// Round 3's probes put the product kernel at 157 us = 112 us of tiles + 43 us of K / V staging, ADDITIVE: a workgroup that stages sits
-// idle (its four waves parked on the loads), so a CU holds 1.4 computing waves per SIMD on average instead of 2, and the tile phases
-// are latency-bound.  A double buffer in LDS does not fit twice per CU (2 x 144 KiB) and one 8 / 16-wave workgroup per CU runs its
-// waves phase-locked (attention_ab.hip, attn_v = 3: 168 us).  Here the two-workgroups-per-CU shape stays -- 4 waves, ONE 72 KiB K / V
-// buffer each -- but a workgroup is persistent and walks the items its XCD deals it: the global loads of item n + 1's K and V rows
-// (18 x 16 bytes per thread) are issued at the START of item n's tiles into registers that nothing reads until the tiles are done;
-// the LDS writes and the barrier pair between two items then find the data landed.  The tile code is the product kernel's, verbatim.
-template <int NT32, int TC, int PREF = 2, int GK = 2>      // PREF: 2 = K and V of the next item prefetched, 1 = K only, 0 = none (A/B); GK: key tiles per fragment group
-__global__ __launch_bounds__(256, 2) void attention_persist_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int width, int batch,
-                                                                   unsigned qkv_bytes) {
-    constexpr int NW = 4, T = TC, TP = NT32 * 32, NT16 = NT32 * 2, NTH = NW * 64;
-    constexpr int NCH = (TP * 8 + NTH - 1) / NTH;
-    constexpr float LOG2E = 1.4426950408889634f;
-    constexpr int nqt = (T + 15) >> 4;
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;
-    char* sV = smem + TP * 128;
-    const int heads = width >> 6;
-    const int xcd = blockIdx.x & 7, nslots = gridDim.x >> 3;          // workgroups are dealt to the XCDs round-robin (speed only)
-    const int nb = batch > xcd ? (batch - xcd + 7) >> 3 : 0;          // images = xcd (mod 8)
-    const int nitems = nb * heads;
-    int m = blockIdx.x >> 3;
-    if (m >= nitems) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ld = 3 * width;
-    const int lrow = lane & 15, lq = lane >> 4;
-    // Every global read goes through ONE buffer descriptor of the whole q | k | v tensor (the host checks that it is below 4 GiB): the
-    // address of a load is a per-lane 32-bit offset that is the same for all of an item's chunks + a scalar offset per chunk, so
-    // the 18 prefetch loads cost two offset registers instead of 18 64-bit pointers (which hipcc spilled: the scratch reloads
-    // carry a vmcnt(0) each and serialised the prefetch).
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, qkv_bytes, 0x00020000);
-    auto item_off = [&](int mm, int& bb, int& hh) -> unsigned {       // byte offset of (image, head)'s first q element (uniform)
-        bb = (mm / heads) * 8 + xcd;
-        hh = mm - (mm / heads) * heads;
-        return ((unsigned)bb * T * ld + hh * 64) * 2u;
-    };
-    const unsigned kv_lane = ((unsigned)(tid >> 3) * ld + (tid & 7) * 8) * 2u;                       // row tid >> 3 of a 32-row chunk, 16-byte piece tid & 7
-    const unsigned kv_lane_last = (((NCH - 1) * 32 + (tid >> 3)) < T ? kv_lane : (unsigned)((T - 1 - (NCH - 1) * 32) * ld + (tid & 7) * 8) * 2u);
-    u32x4 kv[NCH], vv[NCH];
-    auto issue_kv = [&](unsigned ioff, bool do_k, bool do_v) {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const unsigned so = ioff + (unsigned)(i * 32) * ld * 2u;                                 // scalar
-            const unsigned vo = ((i + 1) * 32 <= T) ? kv_lane : kv_lane_last;                        // pad rows re-read the last valid row (zeroed at the LDS write)
-            if (do_k) kv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so + width * 2u, 0);
-            if (do_v) vv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so + width * 4u, 0);
-        }
-    };
-    auto write_kv = [&]() {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int idx = tid + i * NTH;
-            const int row = idx >> 3, c = idx & 7;
-            if (idx < TP * 8) {
-                const unsigned keep = row < T ? 0xffffffffu : 0u;
-                u32x4 a = kv[i], b2 = vv[i];
-                a.x &= keep; a.y &= keep; a.z &= keep; a.w &= keep;
-                b2.x &= keep; b2.y &= keep; b2.z &= keep; b2.w &= keep;
-                *(u32x4*)(sK + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = a;
-                *(u32x4*)(sV + row * 128 + ((c ^ (((row >> 1) & 3) << 1)) << 4)) = b2;
-            }
-        }
-    };
-    const unsigned q_lane = ((unsigned)lrow * ld + lq * 8) * 2u;                                     // query row lrow of a 16-row tile, d = 8 lq .. (+ 32 for the second k step)
-    auto load_q = [&](unsigned ioff, int qt, bf16x8 (&dst)[2]) {                                     // rows beyond T re-read row T - 1 (never stored)
-        const unsigned so = ioff + (unsigned)(qt * 16) * ld * 2u;
-        const unsigned vo = (qt * 16 + lrow < T) ? q_lane : (unsigned)(((T - 1 - qt * 16) * ld + lq * 8) * 2);
-        union { u32x4 u; bf16x8 v; } c0, c1;
-        c0.u = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
-        c1.u = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so + 64u, 0);
-        dst[0] = c0.v; dst[1] = c1.v;
-    };
-    int b, h;
-    unsigned ioff = item_off(m, b, h);
-    bf16x8 qn[2];
-    load_q(ioff, wid, qn);
-    issue_kv(ioff, PREF >= 1, PREF >= 2);
-    // one 16-query tile against the K / V image in LDS (the product kernel's tile code)
-    auto do_tile = [&](const int qt, const bf16x8 (&qf)[2]) {
-        const int q = qt * 16 + lrow;
-            constexpr int G = GK;                             // (the product kernel reads 3 key tiles ahead)
-            constexpr int NG = NT16 / G;
-            f32x4 s[NT16];
-            bf16x8 kfr[2][G][2];
-            auto load_group = [&](int g, bf16x8 (&dst)[G][2]) {
-#pragma unroll
-                for (int j = 0; j < G; ++j)
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-                        dst[j][kk] = *(const bf16x8*)(sK + ((g * G + j) * 16 + lrow) * 128 + (((kk * 4 + lq) ^ (lrow >> 1)) << 4));
-            };
-            load_group(0, kfr[0]);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (g + 1 < NG && (g + 1) * G * 16 < T) load_group(g + 1, kfr[(g + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < G; ++j) {
-                    const int t = g * G + j;
-                    s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (t * 16 < T) {
-                        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[g & 1][j][0], qf[0], s[t], 0, 0, 0);
-                        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[g & 1][j][1], qf[1], s[t], 0, 0, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            float mx = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < NT16; ++t) {
-                const bool partial = (t + 1) * 16 > T;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (partial) {
-                        const int key = t * 16 + lq * 4 + r;
-                        s[t][r] = key < T ? s[t][r] : -INFINITY;
-                    }
-                    mx = fmaxf(mx, s[t][r]);
-                }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mxl = mx * LOG2E;
-            f32x2_t sum2 = {0.f, 0.f};
-            const f32x2_t l2 = {LOG2E, LOG2E}, nm = {-mxl, -mxl};
-#pragma unroll
-            for (int t = 0; t < NT16; ++t) {
-                f32x2_t a = f32x2_t{s[t][0], s[t][1]} * l2 + nm, c = f32x2_t{s[t][2], s[t][3]} * l2 + nm;
-                a.x = __builtin_amdgcn_exp2f(a.x); a.y = __builtin_amdgcn_exp2f(a.y);
-                c.x = __builtin_amdgcn_exp2f(c.x); c.y = __builtin_amdgcn_exp2f(c.y);
-                s[t][0] = a.x; s[t][1] = a.y; s[t][2] = c.x; s[t][3] = c.y;
-                sum2 += a;
-                sum2 += c;
-            }
-            f32x4 o[4];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            bf16x8 vfr[2][4];
-            auto load_v = [&](int u, bf16x8 (&dst)[4]) {
-                const int ra = u * 32 + lq * 4 + (lrow >> 2);
-                const int rb = ra + 16;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const int c = dt * 2 + ((lrow & 3) >> 1);
-                    const bf16x4 va = lds_read_tr16(sV + ra * 128 + ((c ^ (((ra >> 1) & 3) << 1)) << 4) + (lrow & 1) * 8);
-                    const bf16x4 vb = lds_read_tr16(sV + rb * 128 + ((c ^ (((rb >> 1) & 3) << 1)) << 4) + (lrow & 1) * 8);
-                    dst[dt][0] = va[0]; dst[dt][1] = va[1]; dst[dt][2] = va[2]; dst[dt][3] = va[3];
-                    dst[dt][4] = vb[0]; dst[dt][5] = vb[1]; dst[dt][6] = vb[2]; dst[dt][7] = vb[3];
-                }
-            };
-            load_v(0, vfr[0]);
-#pragma unroll
-            for (int u = 0; u < NT32; ++u) {
-                if (!(u * 32 < T)) continue;
-                if (u + 1 < NT32 && (u + 1) * 32 < T) load_v(u + 1, vfr[(u + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                union { bf16x8 v; uint32_t w[4]; } pf;
-                pf.w[0] = pack_bf16x2(s[2 * u][0], s[2 * u][1]);
-                pf.w[1] = pack_bf16x2(s[2 * u][2], s[2 * u][3]);
-                pf.w[2] = pack_bf16x2(s[2 * u + 1][0], s[2 * u + 1][1]);
-                pf.w[3] = pack_bf16x2(s[2 * u + 1][2], s[2 * u + 1][3]);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[u & 1][dt], pf.v, o[dt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            float sum = sum2.x + sum2.y;
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
-            if (q < T) {
-                const float inv = 1.0f / sum;
-                bf16_t* dst = out + ((size_t)b * T + q) * width + h * 64 + lq * 4;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    uint2 pk;
-                    pk.x = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
-                    pk.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
-                    *(uint2*)(dst + dt * 16) = pk;
-                }
-            }
-    };
-    while (true) {
-        if (PREF < 2) issue_kv(ioff, PREF < 1, true);        // A/B forms: (part of) the staging at the item's start, as the one-item kernel does
-        write_kv();
-        __syncthreads();
-        const int mn = m + nslots;
-        const bool more = mn < nitems;                       // uniform
-        int bn = b, hn = h;
-        unsigned noff = ioff;
-        // The first tile is peeled off the loop and its Q is made to have LANDED before the prefetch is queued: vmcnt counts in order,
-        // so a wait for Q behind the 18 prefetch loads would be a wait for all of them (inside the loop hipcc's merged counters give
-        // vmcnt(0) at the loop head either way: by tile 2 the prefetch has had a whole tile of flight).
-        bf16x8 qf0[2] = {qn[0], qn[1]};
-        asm volatile("" : "+v"(qf0[0]), "+v"(qf0[1]));
-        if (more) {
-            noff = item_off(mn, bn, hn);
-            if (PREF >= 1) issue_kv(noff, true, PREF >= 2);  // in flight across this item's tiles; first read by write_kv() above
-        }
-        asm volatile("" ::: "memory");                       // the loads stay here: hipcc may not sink them to their use
-        load_q(ioff, wid + NW, qn);                          // (every wave has at least four tiles at T = 257)
-        do_tile(wid, qf0);
-        for (int qt = wid + NW; qt < nqt; qt += NW) {
-            bf16x8 qf[2] = {qn[0], qn[1]};
-            if (qt + NW < nqt) load_q(ioff, qt + NW, qn);
-            else if (more) load_q(noff, wid, qn);            // this wave's last tile: the first tile of the next item
-            do_tile(qt, qf);
-        }
-        if (!more) break;
-        __syncthreads();                                     // every wave is done with this item's K / V image
-        m = mn; ioff = noff; b = bn; h = hn;
-    }
-}
-
-// The attention experiments of rounds 2-3 (32-query tiles on the 32x32x16 MFMA, eight waves, persistent LDS-DMA staging, two tiles
-// sharing fragments, six waves, the s_memtime-stamped build) live in attention_ab.hip / behind KEMR_AB_VARIANTS: they are built only
+// The attention experiments of rounds 2-4 (32-query tiles on the 32x32x16 MFMA, eight waves, persistent LDS-DMA staging, two tiles
+// sharing fragments, persistent workgroups with the next item's K / V prefetched into registers, six waves, the s_memtime-stamped
+// build) live in attention_ab.hip / behind KEMR_AB_VARIANTS: they are built only
 // by `build.py --ab-variants`; the product library holds ONE attention kernel per shape and kemr_debug_set refuses the others.
-int g_attn_v = 0;          // A/B builds only (attention_ab.hip), T = 257: 0 = the product kernel, 1..4 = the experiments
+int g_attn_v = 0;          // A/B builds only (attention_ab.hip), T = 257: 0 = the product kernel, 1..5 = the experiments
 
 int g_attn_xcd = 1;        // 1 = the images dealt to the XCDs (attn_item above; default), 0 = grid order (tools)
 int g_attn_waves = 0;      // tools: 0 = the default choice below, else waves per workgroup for the 257-token shape (4 or 6)
@@ -507,23 +292,6 @@ static int launch_nt(const bf16_t* qkv, bf16_t* out, int batch, int t, int width
         else kern = attention_kernel<NT32, true, 0>;
     } else if (NT32 == 9 && t == 257) {
 #ifdef KEMR_AB_VARIANTS
-        if (g_attn_v == 5) {                                   // round 4: persistent, next item's K / V prefetched into registers
-            int dev = 0, num_cu = 0;
-            KEMR_CHECK_HIP(hipGetDevice(&dev));
-            KEMR_CHECK_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-            void (*kp)(const bf16_t*, bf16_t*, int, int, unsigned) = attention_persist_kernel<NT32, NT32 == 9 ? 257 : 1>;
-            if (g_attn_waves == 1) kp = attention_persist_kernel<NT32, NT32 == 9 ? 257 : 1, 2, 3>;
-            if (g_attn_waves == 2) kp = attention_persist_kernel<NT32, NT32 == 9 ? 257 : 1, 0, 3>;
-            if (g_attn_waves == 3) kp = attention_persist_kernel<NT32, NT32 == 9 ? 257 : 1, 1, 3>;
-            if (g_attn_waves == 4) kp = attention_persist_kernel<NT32, NT32 == 9 ? 257 : 1, 0, 2>;
-            const int pgrid = (num_cu >= 8 ? num_cu / 8 * 8 : 8) * 2;       // two workgroups per CU
-            KEMR_CHECK_HIP(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            const size_t qkv_bytes = (size_t)batch * t * 3 * width * 2;
-            if (qkv_bytes >= (1ull << 32)) KEMR_FAIL(KEMR_ERR_INVALID, "attention (persistent): the q | k | v tensor must stay below 4 GiB (%zu bytes)", qkv_bytes);
-            hipLaunchKernelGGL(kp, dim3(pgrid), dim3(256), smem, stream, qkv, out, width, batch, (unsigned)qkv_bytes);
-            KEMR_CHECK_LAUNCH("attention_persist_kernel");
-            return KEMR_OK;
-        }
         if (g_attn_v != 0) return launch_attention_ab(g_attn_v, g_attn_waves, qkv, out, batch, width, xbatch, stream);
         if (g_attn_waves == 6) { kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, NT32 == 9 ? 6 : 4>; threads = 384; }
         else if (g_attn_waves == 2 && xbatch) kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, 4, NT32 == 9>;   // stamps: the caller's
