@@ -59,10 +59,10 @@ class ClipEngine:
     """One packed CLIP model (both towers) in HBM."""
 
     def __init__(self, arch: ClipArch, device: torch.device | str = "cuda:0", precision: str = _lib.DEFAULT_PRECISION):
-        """precision: "bf16" (default: bf16 operands, fp32 accumulation, fp32 residual stream), "bf16-res16" (bf16 residual
-        stream, opt-in), "fp8" (QKV GEMMs on fp8 operands, BASELINE config 5), "fp8-res16" or "fp8-mlp" (fc1 too); "bf16-x24" /
-        "fp8-x24": bf16 / fp8 with the fp32 residual stream stored as 24-bit floats (opt-in; model option residual_stream_24bit).
-        See kemr_precision in include/kemr.h."""
+        """precision: "bf16-x24" (default: bf16 operands, fp32 accumulation, the fp32 residual stream stored as 24-bit floats -- model
+        option residual_stream_24bit), "bf16" (the stream as 4-byte fp32), "bf16-res16" (bf16 residual stream, opt-in), "fp8" / "fp8-x24"
+        (the vision tower's QKV GEMMs on fp8 operands, BASELINE config 5), "fp8-res16" or "fp8-mlp" (fc1 too).  See kemr_precision in
+        include/kemr.h and _lib.DEFAULT_PRECISION."""
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
         self.precision = precision

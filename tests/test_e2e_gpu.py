@@ -112,7 +112,7 @@ def test_hip_path_end_to_end_against_oracle_and_reference_metrics(device, name, 
         assert abs(float(np.abs(v.astype(np.float64)).sum()) - want) < 2e-5 * want, k          # same oracle as the fixture's (thread count moves fp32 sums by 1e-7)
         assert float(np.abs(v[:8] - z["first8_" + k]).max()) < 5e-6, k
     # ---- the product path: HIP encoders (default precision), embeddings stay in HBM
-    assert _lib.DEFAULT_PRECISION == "bf16"
+    assert _lib.DEFAULT_PRECISION == "bf16-x24"            # round 4: the fp32 residual stream stored as 24-bit floats (what the drop-in modules run)
     eng = engine.ClipEngine(ARCHS[name], device)
     eng.load_state_dict(sd)
     he = {"image": eng.encode_image(px.to(device), normalize=True), "query": eng.encode_text(q_ids.to(device), normalize=True),

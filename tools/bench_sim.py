@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--routes", default="0,1")
-    ap.add_argument("--kl", default="1", help="K loops of the list pass to time, e.g. 0,1 (debug switch gemm_kl)")
+    ap.add_argument("--kl", default="0", help="K loops of the list pass to time, e.g. 0,1 (debug switch gemm_kl; 1 needs a build.py --ab-variants library)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--stamps", action="store_true", help="in-kernel cycle split of the list pass (stamped instantiation)")
     ap.add_argument("--device-rng", action="store_true", help="the data bench.py uses (device generator, seed 7)")
@@ -69,7 +69,7 @@ def main():
                               "same_as_first": same, "nq": args.nq, "ng": args.ng, "kdim": qp.kdim, "k": args.k,
                               "lists": dict(zip(("flag", "longest", "cap", "chunks", "sampled", "records_per_query"), list(st)))}))
     debug.set("sim_lists", 1)
-    debug.set("gemm_kl", 1)
+    debug.set("gemm_kl", 0)
     if args.stamps:
         import ctypes as C
         import numpy as np

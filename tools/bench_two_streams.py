@@ -79,6 +79,9 @@ res = {k: [] for k in legs}
 # results must not depend on the arrangement
 torch.cuda.synchronize()
 ref = A.encode_image(px[:254], normalize=True)
+torch.cuda.synchronize()        # an engine's workspace belongs to ONE call at a time: the next call on another stream must not start
+                                # while this one runs (the first version of this script did not wait here: two calls scribbled over
+                                # each other's pool_idx / row_start rows in the shared workspace and a gather faulted)
 with torch.cuda.stream(sA):
     a = A.encode_image(px[:127], normalize=True)
 with torch.cuda.stream(sB):
