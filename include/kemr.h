@@ -116,11 +116,13 @@ int kemr_model_destroy(kemr_model* m);
  *                      row alone (2 instead of 12 W^2 of GEMM work per token row in that block).  The pooled rows see the same
  *                      arithmetic in smaller launches.  Applies with store-only epilogues and fc1 on bf16 (not KEMR_PREC_FP8_MLP); 0 = every row
  *                      through every block, as the reference computes it.
- *   "residual_stream_24bit"  (set BEFORE kemr_model_finalize; default 0, KEMR_STREAM24=1 in the environment at create makes it 1):
- *                      the fp32 residual stream of KEMR_PREC_BF16 / FP8 / FP8_MLP is stored as 24-bit floats -- the upper three
- *                      bytes of the fp32, rounded to nearest: 15 mantissa bits, 128 x finer than bf16 -- 3 instead of 4 bytes per
- *                      element in the HBM-bound LayerNorm passes (+2 % on the ViT-L/14 step).  Opt-in: inside the fixed 0.2-point
- *                      Recall@10 bar, but not bit-compatible with the default. */
+ *   "residual_stream_24bit"  (set BEFORE kemr_model_finalize; default 1 since round 4, KEMR_STREAM24=0 in the environment at create
+ *                      makes it 0): the fp32 residual stream of KEMR_PREC_BF16 / FP8 / FP8_MLP is stored as 24-bit floats -- the
+ *                      upper three bytes of the fp32, rounded to nearest: 15 mantissa bits, 128 x finer than bf16 -- 3 instead of
+ *                      4 bytes per element in the HBM-bound LayerNorm passes (+2 % on the ViT-L/14 step); every statistic and add
+ *                      stays fp32 arithmetic.  The default because it meets every bar the 4-byte stream meets (1 - cos against the
+ *                      fp32 oracle on plain and heavy-tailed weights, the fixed 0.2-point Recall@10 bar on ViT-B/32 and ViT-L/14,
+ *                      the end-to-end margin rule: DESIGN.md section 2); 0 = the 4-byte stream (python: precision "bf16"). */
 int kemr_model_set_option(kemr_model* m, const char* key, int value);
 int kemr_model_get_option(const kemr_model* m, const char* key, int* value);
 /* number of required tensor names; name i via kemr_model_tensor_name (for strict-load diagnostics) */

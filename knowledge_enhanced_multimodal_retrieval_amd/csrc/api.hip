@@ -75,7 +75,7 @@ struct kemr_model {
     int fp8 = 0;                                    // bit 0: QKV on fp8 operands (KEMR_PREC_FP8), bit 1: fc1 too (KEMR_PREC_FP8_MLP)
     int resadd = 1;                                 // option "residual_fusion": residual add inside the out-proj / fc2 epilogues
     int last_pooled = 1;                            // option "last_block_pooled_row": the last block's query path on the pooled row only
-    int stream24 = 0;                               // option "residual_stream_24bit" (before finalize): the fp32-class stream stored in 3 bytes
+    int stream24 = 1;                               // option "residual_stream_24bit" (before finalize; default on since round 4): the fp32-class stream stored in 3 bytes
     // vision
     TowerW vis;
     const bf16_t* conv_w = nullptr;
@@ -139,7 +139,7 @@ extern "C" int kemr_model_create(const kemr_cfg* cfg, kemr_model** out) {
     m->cfg = *cfg;
     { const char* v = getenv("KEMR_RESADD"); const int e = (v && *v) ? atoi(v) : 1; m->resadd = e < 0 ? 0 : e > 2 ? 2 : e; }
     { const char* v = getenv("KEMR_LAST_BLOCK_FULL"); m->last_pooled = (v && *v && atoi(v) != 0) ? 0 : 1; }
-    { const char* v = getenv("KEMR_STREAM24"); m->stream24 = (v && *v && atoi(v) != 0) ? 1 : 0; }
+    { const char* v = getenv("KEMR_STREAM24"); m->stream24 = (v && *v) ? (atoi(v) != 0 ? 1 : 0) : 1; }
     m->grid = cfg->image_size / cfg->patch;
     m->patches = m->grid * m->grid;
     m->kpad = (int)round_up(3 * cfg->patch * cfg->patch, 64);

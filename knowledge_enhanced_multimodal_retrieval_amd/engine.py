@@ -131,8 +131,8 @@ class ClipEngine:
             shape = (C.c_int64 * max(host.dim(), 1))(*host.shape)
             _lib.check(self._L.kemr_model_load_tensor(self._h, name.encode(), C.c_void_p(host.data_ptr()), _lib.KEMR_F32,
                                                       shape, host.dim()), f"load_tensor({name})")
-        if self.precision.endswith("-x24"):
-            _lib.check(self._L.kemr_model_set_option(self._h, b"residual_stream_24bit", 1), "model_set_option")
+        # "-x24" names the 24-bit stream (the product's default), "bf16" / "fp8" / "fp8-mlp" the 4-byte one; idle for the bf16 streams
+        _lib.check(self._L.kemr_model_set_option(self._h, b"residual_stream_24bit", 1 if self.precision.endswith("-x24") else 0), "model_set_option")
         with torch.cuda.device(self.device):
             _lib.check(self._L.kemr_model_finalize(self._h, _lib.PRECISIONS[self.precision]), "model_finalize")
         self.ready = True

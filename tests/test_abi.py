@@ -54,10 +54,10 @@ def test_model_options_and_debug_switches_are_separate():
     assert lib.kemr_model_get_option(h1, b"last_block_pooled_row", C.byref(v)) == 0 and v.value == 1
     assert lib.kemr_model_set_option(h1, b"last_block_pooled_row", 0) == 0 and lib.kemr_model_set_option(h1, b"last_block_pooled_row", 2) == -1
     assert lib.kemr_model_get_option(h2, b"last_block_pooled_row", C.byref(v)) == 0 and v.value == 1
+    assert lib.kemr_model_get_option(h1, b"residual_stream_24bit", C.byref(v)) == 0 and v.value == 1          # the default since round 4
+    assert lib.kemr_model_set_option(h1, b"residual_stream_24bit", 0) == 0 and lib.kemr_model_set_option(h1, b"residual_stream_24bit", 2) == -1
     assert lib.kemr_model_get_option(h1, b"residual_stream_24bit", C.byref(v)) == 0 and v.value == 0
-    assert lib.kemr_model_set_option(h1, b"residual_stream_24bit", 1) == 0 and lib.kemr_model_set_option(h1, b"residual_stream_24bit", 2) == -1
-    assert lib.kemr_model_get_option(h1, b"residual_stream_24bit", C.byref(v)) == 0 and v.value == 1
-    assert lib.kemr_model_get_option(h2, b"residual_stream_24bit", C.byref(v)) == 0 and v.value == 0
+    assert lib.kemr_model_get_option(h2, b"residual_stream_24bit", C.byref(v)) == 0 and v.value == 1
     lib.kemr_model_destroy(h1)
     lib.kemr_model_destroy(h2)
     before = {k: debug.get(k) for k in debug.KEYS}

@@ -34,6 +34,7 @@ ids = torch.cat([bench.synthetic_ids(arch, 255, 5), bench.synthetic_ids(arch, 25
 lens = engine.text_lengths(ids)
 ids_d = ids.to(dev)
 sA, sB = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+sHi, sLo = torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev, priority=0)      # the texts beside the images at a higher / the same priority
 
 
 def leg_one(n):
@@ -74,7 +75,23 @@ def leg_it_par(n):
     return (255 + 1501) * n
 
 
-legs = {"one": leg_one, "halves": leg_halves, "streams": leg_streams, "it-seq": leg_it_seq, "it-par": leg_it_par}
+def leg_it_par_main(n):          # the product's arrangement: images on the caller's (default) stream, texts on a side stream
+    for _ in range(n):
+        A.encode_image(px, normalize=True)
+        with torch.cuda.stream(sB):
+            Bn.encode_text(ids_d, normalize=True, lens=lens)
+    return (255 + 1501) * n
+
+
+def leg_it_par_hi(n):            # the text stream at high priority
+    for _ in range(n):
+        A.encode_image(px, normalize=True)
+        with torch.cuda.stream(sHi):
+            Bn.encode_text(ids_d, normalize=True, lens=lens)
+    return (255 + 1501) * n
+
+
+legs = {"it-par-main": leg_it_par_main, "it-par-hi": leg_it_par_hi, "one": leg_one, "halves": leg_halves, "streams": leg_streams, "it-seq": leg_it_seq, "it-par": leg_it_par}
 res = {k: [] for k in legs}
 # results must not depend on the arrangement
 torch.cuda.synchronize()
