@@ -175,7 +175,6 @@ def main():
     ap.add_argument("--text-group", type=int, default=0, help="texts per encoder call (0 = engine.tile_friendly_batch: 851 for ViT-L/14; 255 = one call per text column and step, round 1 / early round 2)")
     ap.add_argument("--full-context", action="store_true", help="compute all 77 positions of every text (the reference's arithmetic; default: only the positions up to the end-of-text token, which are the ones that can reach the embedding)")
     ap.add_argument("--resadd", type=int, default=-1, help="A/B: 1 / 0 = residual add inside the out-proj / fc2 epilogues on / off (default: the library's setting)")
-    ap.add_argument("--single-stream", action="store_true", help="queue the text calls behind the image calls on one stream (default: texts on a side stream beside the images, as evaluators.encode_dataset does)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sim", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the host-pipeline sub-result (N = 1: uint8 sources through encode_dataset)")
@@ -256,14 +255,9 @@ def main():
     text_group = main_pool.group
 
     all_calls = []                 # every encoder call of this process, in order: (kind, items, resadd bytes, token rows)
-    # Text calls on a side stream beside the image calls (round 4; what evaluators.encode_dataset does): the towers are independent and a
-    # quarter of a call is HBM-bound work with the matrix cores idle, which the other tower's GEMMs fill in part (tools/bench_two_streams.py)
-    main_stream = torch.cuda.current_stream(dev)
-    side_stream = None if (args.single_stream or os.environ.get("KEMR_TEXT_STREAM", "1") == "0") else torch.cuda.Stream(dev)
 
     class Stepper:
-        def __init__(self, e, resadd, pool=None, side=side_stream):
-            self.side = side
+        def __init__(self, e, resadd, pool=None):
             self.pool = pool or main_pool
             self.resadd = (2 if e.precision.endswith("res16") else 4) if resadd else 0      # bytes per in-place C element, census
             self.e, self.pending, self.images, self.texts, self.calls = e, 0, 0, 0, all_calls      # pooled texts; items encoded so far; the process-wide call list
@@ -279,7 +273,7 @@ def main():
             p = self.pool
             self.e.pack_text = p.packed
             while self.pending >= p.group:
-                self._text(p.ids, p.lens)
+                self.e.encode_text(p.ids, normalize=True, lens=p.lens)
                 self.calls.append(("text", p.group, self.resadd, p.rows(p.group), self.pooled))
                 self.pending -= p.group
                 self.texts += p.group
@@ -290,20 +284,13 @@ def main():
             if self.pending:
                 p = self.pool
                 self.e.pack_text = p.packed
-                self._text(p.ids[:self.pending], p.lens[:self.pending])
+                self.e.encode_text(p.ids[:self.pending], normalize=True, lens=p.lens[:self.pending])
                 self.calls.append(("text", self.pending, self.resadd, p.rows(self.pending), self.pooled))
                 self.texts += self.pending
                 self.text_rows += p.rows(self.pending)
                 self.pending = 0
 
-        def _text(self, ids_, lens_):
-            if self.side is None:
-                return self.e.encode_text(ids_, normalize=True, lens=lens_)
-            with torch.cuda.stream(self.side):           # (the pool's ids are static and were uploaded before the first barrier)
-                return self.e.encode_text(ids_, normalize=True, lens=lens_)
-
         def check_outputs(self):            # the step's own items, for the oracle / cross-precision comparisons (untimed)
-            torch.cuda.synchronize(dev)
             pk = self.pool.packed
             self.e.pack_text = pk
             self.calls += [("image", B, self.resadd, B * arch.v_tokens, self.pooled), ("text", B, self.resadd, int(q_lens.sum()) if pk else B * arch.ctx, self.pooled),
@@ -489,33 +476,6 @@ def main():
     }
     result["kernel_ms_per_step"] = {"gemm": ms[0], "layernorm": ms[1], "attention": ms[2], "embed_tail": ms[3]}
     result["config"]["residual_add_in_gemm_epilogue"] = resadd_on
-    result["config"]["text_calls_on"] = "a side stream beside the image calls" if side_stream is not None else "the image calls' stream"
-    if side_stream is not None:
-        # the per-class hipEvent times above were taken with the two towers' kernels overlapping (a kernel that shares the chip takes
-        # longer than alone); the same 10 steps on ONE stream give the kernels' own durations, which is what the roofline fraction of the
-        # dominant kernel is quoted on -- and the step rate without the side stream, for the record
-        s1 = Stepper(eng, resadd_on, side=None)
-        for _ in range(3):
-            s1.step()
-        s1.drain()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(20):
-            s1.step()
-        s1.drain()
-        barrier()
-        dt1 = max_over_ranks(time.perf_counter() - t1)
-        ms1, gemm_n1, gemm_flops1 = profile_region(s1)
-        a1 = gemm_flops1 / (ms1[0] * 1e-3) / 1e12
-        result["roofline"]["overlapped"] = {"achieved": achieved, "frac": achieved / PEAK_BF16_TFLOPS, "avg_launch_us": 1e3 * gemm_ms / max(gemm_n, 1),
-                                            "kernel_ms_per_step": result["kernel_ms_per_step"],
-                                            "what": "the GEMM class timed while the text tower's kernels run beside the image tower's (the timed region's arrangement)"}
-        result["roofline"].update({"achieved": a1, "frac": a1 / PEAK_BF16_TFLOPS, "launches_per_step": round(gemm_n1, 1), "avg_launch_us": 1e3 * ms1[0] / max(gemm_n1, 1),
-                                   "flops_per_launch": gemm_flops1 / max(gemm_n1, 1),
-                                   "measured_on": "10 steps with every call on one stream (a kernel's own duration); `overlapped` holds the same measurement in the timed region's two-stream arrangement"})
-        result["kernel_ms_per_step"] = {"gemm": ms1[0], "layernorm": ms1[1], "attention": ms1[2], "embed_tail": ms1[3]}
-        result["single_stream"] = {"items_per_s": 3 * B * world * 20 / dt1, "ms_per_step": 1e3 * dt1 / 20, "steps": 20,
-                                   "side_stream_speedup": value / (3 * B * world * 20 / dt1)}
 
     pipeline_leg()
 

@@ -161,23 +161,10 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
     n_txt = ENCODE_ITEMS if arch is None else max(1, engine.tile_friendly_batch(arch.ctx, arch.t_width, ENCODE_ITEMS, engine.MAX_TEXT_BATCH) // 2)
     pend_i, pend_q, pend_t, pend_ql, pend_tl = [], [], [], [], []
     count = {"i": 0, "t": 0, "rows": 0}
-    # The text calls run on a SIDE stream beside the image calls (round 4; KEMR_TEXT_STREAM=0: everything on the caller's stream).
-    # The two towers are independent, and a quarter of an encoder call is HBM-bound work with the matrix cores idle (LayerNorm,
-    # attention staging): the text tower's LayerNorm and attention workgroups fit beside a vision GEMM's one workgroup per CU (no or
-    # 24 KiB of LDS against its 128 KiB) and the other way round -- measured +3.6 % items/s for one step's worth of images and texts
-    # (tools/bench_two_streams.py, profiles/r04_two_streams.txt).  Same kernels, same inputs: the embeddings do not change.
-    main = torch.cuda.current_stream(device) if device.type == "cuda" else None
-    side = torch.cuda.Stream(device) if main is not None and os.environ.get("KEMR_TEXT_STREAM", "1") != "0" else None
-
-    def encode_text_side(ids_in, lens_in=None):
-        if side is None:
-            return model.encode_text(ids_in, normalize=True, lens=lens_in) if lens_in is not None else model.encode_text(ids_in, normalize=True)
-        side.wait_stream(main)                         # the ids were uploaded and concatenated on the caller's stream
-        ids_in.record_stream(side)                     # ... and must not be handed out again before the side stream has read them
-        with torch.cuda.stream(side):
-            both_ = model.encode_text(ids_in, normalize=True, lens=lens_in) if lens_in is not None else model.encode_text(ids_in, normalize=True)
-        both_.record_stream(main)                      # consumed on the caller's stream behind main.wait_stream(side) below
-        return both_
+    # (Round 4 measured the text calls on a SIDE stream beside the image calls -- tools/bench_two_streams.py, profiles/r04_two_streams.txt:
+    # +3.2 % items/s when every image call has a text call beside it, +0.7 % in the bench's mix of one text call per three image calls,
+    # consecutive image calls on two streams +1.4 % -- and left it out: the persistent GEMM takes every CU's LDS, so only the HBM-bound
+    # kernels of the other tower fit beside it, and a gain of that size does not pay for two-stream bookkeeping in every caller.)
     # Packed text calls (engine.ClipEngine.encode_text: a text is computed up to its end-of-text token only): the tokenizer-side
     # lengths travel with the ids, and a call takes as many (query, target) pairs as fill engine.TEXT_ROW_BUDGET token rows.
     by_rows = bool(getattr(model, "accepts_text_lengths", False)) and arch is not None and arch.ctx <= 128 and \
@@ -203,7 +190,7 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
                 s1 = s0 + max(1, int((pair_rows[s0:] - base <= engine.TEXT_ROW_BUDGET).sum()))
                 if s1 >= count["t"] and not final:
                     break                                                          # not a whole call yet: wait for more
-                both = encode_text_side(torch.cat([cq[s0:s1], ct[s0:s1]]), torch.cat([lq[s0:s1], lt[s0:s1]]))
+                both = model.encode_text(torch.cat([cq[s0:s1], ct[s0:s1]]), normalize=True, lens=torch.cat([lq[s0:s1], lt[s0:s1]]))
                 qry.append(both[: s1 - s0])
                 tgt.append(both[s1 - s0:])
                 base, s0 = int(pair_rows[s1 - 1]), s1
@@ -217,7 +204,7 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
         cq, ct = torch.cat(pend_q), torch.cat(pend_t)
         for s0 in range(0, take, n_txt):                                           # queries and targets of n_txt items in ONE call
             s1 = min(take, s0 + n_txt)
-            both = encode_text_side(torch.cat([cq[s0:s1], ct[s0:s1]]))
+            both = model.encode_text(torch.cat([cq[s0:s1], ct[s0:s1]]), normalize=True)
             qry.append(both[: s1 - s0])
             tgt.append(both[s1 - s0:])
         pend_q[:], pend_t[:] = [cq[take:]], [ct[take:]]
@@ -246,8 +233,6 @@ def encode_dataset(model, dataset, batch_size: int = 64, seed: int = 42, num_wor
             flush_texts(False)
     flush_images(True)
     flush_texts(True)
-    if side is not None:
-        main.wait_stream(side)                         # the text embeddings are complete before anything on the caller's stream reads them
     return torch.cat(img), torch.cat(qry), torch.cat(tgt), uuids
 
 

@@ -91,7 +91,31 @@ def leg_it_par_hi(n):            # the text stream at high priority
     return (255 + 1501) * n
 
 
-legs = {"it-par-main": leg_it_par_main, "it-par-hi": leg_it_par_hi, "one": leg_one, "halves": leg_halves, "streams": leg_streams, "it-seq": leg_it_seq, "it-par": leg_it_par}
+def leg_alt255(n):               # consecutive 255-image calls alternate between two streams (two engines = two workspaces)
+    for i in range(n):
+        if i % 2 == 0:
+            with torch.cuda.stream(sA):
+                A.encode_image(px, normalize=True)
+        else:
+            with torch.cuda.stream(sB):
+                Bn.encode_image(px, normalize=True)
+    return 255 * n
+
+
+def leg_alt255_text(n):          # the same with the texts on a third stream (another engine would be needed for a clean split: here the
+    for i in range(n):           # texts share engine B's text workspace only, which the image calls do not touch)
+        if i % 2 == 0:
+            with torch.cuda.stream(sA):
+                A.encode_image(px, normalize=True)
+        else:
+            with torch.cuda.stream(sB):
+                Bn.encode_image(px, normalize=True)
+        with torch.cuda.stream(sHi):
+            Bn.encode_text(ids_d, normalize=True, lens=lens)
+    return (255 + 1501) * n
+
+
+legs = {"alt-255": leg_alt255, "alt-255+text": leg_alt255_text, "it-par-main": leg_it_par_main, "it-par-hi": leg_it_par_hi, "one": leg_one, "halves": leg_halves, "streams": leg_streams, "it-seq": leg_it_seq, "it-par": leg_it_par}
 res = {k: [] for k in legs}
 # results must not depend on the arrangement
 torch.cuda.synchronize()
