@@ -114,10 +114,14 @@ def usable_loader_workers(dataset, collate, num_workers: int) -> int:
     num_workers = max(1, num_workers // _local_world_size())
     if os.environ.get("KEMR_LOADER_CONTEXT", "forkserver") == "fork":
         return num_workers
-    import io
     import pickle
+
+    class _Discard:                                            # a big in-memory split is serialised once here (as it will be once per
+        def write(self, b):                                    # worker by the loader), but never held: the bytes are dropped
+            return len(b)
+
     try:
-        pickle.dump((dataset, collate), io.BytesIO(), protocol=pickle.HIGHEST_PROTOCOL)
+        pickle.Pickler(_Discard(), protocol=pickle.HIGHEST_PROTOCOL).dump((collate, dataset))
     except Exception as e:                                     # noqa: BLE001 - anything that cannot cross to a fresh process
         logger.warning(f"loader workers need a picklable dataset / tokenize_fn ({type(e).__name__}: {e}); using num_workers=0")
         return 0
