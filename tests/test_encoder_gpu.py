@@ -21,6 +21,23 @@ def _cos(a, b):
 PRECISIONS = ["bf16", "bf16-res16", "bf16-x24"]     # fp32 / bf16 / 24-bit-float residual stream (include/kemr.h kemr_precision, options)
 
 
+_ORACLE_CACHE = {}
+
+
+def _oracle(name, nimg, ntxt, outliers=False):
+    """(state dict, pixels, ids, oracle image / text embeddings) of the small full-size cases, computed once per session: the fp32
+    CPU oracle takes seconds per ViT-L/14 item and the precision-parametrised tests all compare against the same numbers."""
+    key = (name, nimg, ntxt, outliers)
+    if key not in _ORACLE_CACHE:
+        oa = clip_ref.ARCHS[name]
+        sd = clip_ref.random_state_dict(oa, seed=0, outliers=outliers)
+        g = torch.Generator().manual_seed(1234)
+        px = torch.randn(nimg, 3, oa["image_size"], oa["image_size"], generator=g)
+        ids = clip_ref.synthetic_ids(oa, ntxt)
+        _ORACLE_CACHE[key] = (sd, px, ids, clip_ref.encode_image(sd, oa, px), clip_ref.encode_text(sd, oa, ids))
+    return _ORACLE_CACHE[key]
+
+
 def _engine(name, device, seed=0, precision="bf16"):
     arch = ARCHS[name]
     sd = clip_ref.random_state_dict(clip_ref.ARCHS[name], seed=seed)
@@ -114,12 +131,10 @@ def test_strict_load_errors(device):
 @pytest.mark.parametrize("name,nimg,ntxt", [("ViT-B/32", 3, 4), ("ViT-L/14", 2, 3)])
 def test_full_size_models_match_oracle(device, name, nimg, ntxt, precision):
     """BASELINE configs[0]/[1] architectures at full width/depth on a few items (the CPU oracle takes seconds)."""
-    arch, sd, eng = _engine(name, device, precision=precision)
-    oa = clip_ref.ARCHS[name]
-    g = torch.Generator().manual_seed(1234)
-    px = torch.randn(nimg, 3, 224, 224, generator=g)
-    ids = clip_ref.synthetic_ids(oa, ntxt)
-    ref_i, ref_t = clip_ref.encode_image(sd, oa, px), clip_ref.encode_text(sd, oa, ids)
+    arch = ARCHS[name]
+    sd, px, ids, ref_i, ref_t = _oracle(name, nimg, ntxt)
+    eng = engine.ClipEngine(arch, device, precision=precision)
+    eng.load_state_dict(sd)
     got_i = eng.encode_image(px.to(device)).cpu()
     got_t = eng.encode_text(ids.to(device)).cpu()
     ci, ct = _cos(got_i, ref_i), _cos(got_t, ref_t)
@@ -141,15 +156,10 @@ def test_heavy_tailed_weights_match_oracle(device, name, nimg, ntxt, precision):
     kernel involved) leaves the fp32 oracle by 3e-2 .. 1e-1 just the same: a statement about the precision class, not testable as
     parity."""
     arch = ARCHS[name]
-    oa = clip_ref.ARCHS[name]
-    sd = clip_ref.random_state_dict(oa, seed=0, outliers=True)
+    sd, px, ids, ref_i, ref_t = _oracle(name, nimg, ntxt, outliers=True)
     assert max(float(v.abs().max()) for k, v in sd.items() if k.endswith("ln_1.weight")) > 25.0
     eng = engine.ClipEngine(arch, device, precision=precision)
     eng.load_state_dict(sd)
-    g = torch.Generator().manual_seed(1234)
-    px = torch.randn(nimg, 3, 224, 224, generator=g)
-    ids = clip_ref.synthetic_ids(oa, ntxt)
-    ref_i, ref_t = clip_ref.encode_image(sd, oa, px), clip_ref.encode_text(sd, oa, ids)
     got_i, got_t = eng.encode_image(px.to(device)).cpu(), eng.encode_text(ids.to(device)).cpu()
     assert bool(torch.isfinite(got_i).all()) and bool(torch.isfinite(got_t).all())
     ci, ct = _cos(got_i, ref_i), _cos(got_t, ref_t)
@@ -199,12 +209,10 @@ def test_fp8_encoders_match_oracle(device, name, nimg, ntxt, precision, tol):
     within 0.2 points of bf16 (next test)."""
     if name == "tiny":
         tol = 5e-3 if precision != "fp8-mlp" else 2e-2
-    arch, sd, eng = _engine(name, device, precision=precision)
-    oa = clip_ref.ARCHS[name]
-    g = torch.Generator().manual_seed(1234)
-    px = torch.randn(nimg, 3, arch.image_size, arch.image_size, generator=g)
-    ids = clip_ref.synthetic_ids(oa, ntxt)
-    ref_i, ref_t = clip_ref.encode_image(sd, oa, px), clip_ref.encode_text(sd, oa, ids)
+    arch = ARCHS[name]
+    sd, px, ids, ref_i, ref_t = _oracle(name, nimg, ntxt)
+    eng = engine.ClipEngine(arch, device, precision=precision)
+    eng.load_state_dict(sd)
     ci, ct = _cos(eng.encode_image(px.to(device)).cpu(), ref_i), _cos(eng.encode_text(ids.to(device)).cpu(), ref_t)
     print(f"{name} {precision}: image 1-cos max {float((1 - ci).max()):.2e}, text 1-cos max {float((1 - ct).max()):.2e}")
     assert float((1 - ci).max()) < tol and float((1 - ct).max()) < tol
