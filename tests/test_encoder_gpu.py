@@ -128,9 +128,10 @@ def test_strict_load_errors(device):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-@pytest.mark.parametrize("name,nimg,ntxt", [("ViT-B/32", 3, 4), ("ViT-L/14", 2, 3)])
+@pytest.mark.parametrize("name,nimg,ntxt", [("ViT-B/32", 3, 4), ("ViT-B/16", 2, 3), ("ViT-L/14", 2, 3)])
 def test_full_size_models_match_oracle(device, name, nimg, ntxt, precision):
-    """BASELINE configs[0]/[1] architectures at full width/depth on a few items (the CPU oracle takes seconds)."""
+    """BASELINE configs[0]/[1] architectures at full width/depth on a few items (the CPU oracle takes seconds), and ViT-B/16 -- the
+    third `--model_name` choice of the reference's CLIs (evaluator.py:264-266): 197 tokens, the run-time-length attention kernel."""
     arch = ARCHS[name]
     sd, px, ids, ref_i, ref_t = _oracle(name, nimg, ntxt)
     eng = engine.ClipEngine(arch, device, precision=precision)
