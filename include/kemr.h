@@ -33,8 +33,11 @@ extern "C" {
 /* 2: kemr_sim_workspace_bytes takes kdim, panels are allocated with ceil256(rows) rows (kemr_panel_build zero-fills up to
  *    256), kemr_model_set_option / kemr_model_get_option, the tools' switches live in kemr_debug.h (kemr_debug_set).
  * 3: kemr_encode_text_packed / kemr_text_packed_workspace_bytes, option "last_block_pooled_row"; kemr_workspace_bytes grows by the
- *    last block's pooled-row area (callers that size their workspace with it need no change). */
-#define KEMR_ABI_VERSION 3
+ *    last block's pooled-row area (callers that size their workspace with it need no change).
+ * 4: the same entry points with changed defaults and semantics: option "residual_stream_24bit" defaults to 1; the fp8 precisions apply
+ *    to the vision tower only and scale the e4m3 A operand per channel; kemr_preprocess_u8_batch accepts 0 x 0 items (an undecodable
+ *    image: zeros after normalisation); kemr_debug_set refuses the experiment kernels the library was built without. */
+#define KEMR_ABI_VERSION 4
 
 typedef enum kemr_status {
     KEMR_OK = 0,

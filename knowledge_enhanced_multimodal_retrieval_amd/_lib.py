@@ -95,7 +95,7 @@ DEBUG_SIGNATURES = {
     "kemr_debug_sim_lists": (_i, [_vp, _i, _i, _i64, _i, _vp]),
     "kemr_debug_gemm_stamps": (_i, [_vp, _i]),
 }
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lock = threading.Lock()
 _lib = None

@@ -33,9 +33,9 @@ def test_header_symbols_are_bound_and_exported():
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r"\bT (kemr_[a-z0-9_]+)", out))
     assert exported == set(names) | set(dbg), "library exports differ from the headers"
-    assert lib.kemr_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.kemr_abi_version() == _lib.ABI_VERSION == 4
     text = open(os.path.join(ROOT, "include", "kemr.h")).read()
-    assert re.search(r"#define\s+KEMR_ABI_VERSION\s+3\b", text)
+    assert re.search(r"#define\s+KEMR_ABI_VERSION\s+4\b", text)
 
 
 def test_model_options_and_debug_switches_are_separate():
