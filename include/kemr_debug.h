@@ -42,6 +42,9 @@ extern "C" {
  *   "sim_lists"     kemr_sim_topk: 0 = never the candidate-list route (nor the fast rank pass for bonus lists), 1 = where it pays
  *                   (default: from 2 048 gallery rows, 256 queries and 1.2e10 multiply-adds up), 3 = wherever it fits, 2 = as 3 and
  *                   the exact fallback forced to run after the lists
+ *   "ln_nt"         LayerNorm cache hints: 3 = deltas and residual rows loaded, the ln_1 write-back of x stored non-temporally (the product
+ *                   kernel); [A/B] 0 = plain (rounds 1-3), 1 = deltas only, 2 = deltas + row loads
+ *   "attn_waves"    also: [A/B] 7 = the vision attention kernel with plain K / V loads (rounds 1-3), 5 = Q rows non-temporal as well
  *   "ab_variants"   read-only: 1 = the library holds the [A/B] kernels */
 int kemr_debug_set(const char* key, int value);
 int kemr_debug_get(const char* key, int* value);

@@ -653,6 +653,7 @@ const DebugKnob* debug_knobs(int* n) {
         {"attn_v", &g_attn_v, 0, 5, 1u << 0},         // 0 = the product kernel, 1..4 = attention_ab.hip: A/B builds
         {"attn_xcd", &g_attn_xcd, 0, 1, ~0u},         // attention: images dealt to the XCDs
         {"attn_waves", &g_attn_waves, 0, 8, 1u << 0}, // waves per attention workgroup at T = 257 (0 = default; others: A/B builds)
+        {"ln_nt", &g_ln_nt, 0, 3, 1u << 3},           // LayerNorm cache hints: 3 = deltas, residual rows and the x write-back non-temporal (the product kernel); 0 / 1 / 2 = earlier levels: A/B builds
         {"sim_lists", sim_lists_knob(), 0, 3, ~0u},   // 0 = never the candidate-list route, 1 = where it pays, 2 = wherever it fits + the fallback forced, 3 = wherever it fits
         {"ab_variants", &g_ab_variants, -1, -2, 0},   // read-only: 1 = this library was built with the A/B experiment kernels
     };

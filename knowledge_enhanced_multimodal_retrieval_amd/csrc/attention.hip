@@ -43,7 +43,16 @@ __device__ __forceinline__ bool attn_item(int xbatch, int& h, int& b) {
     return b < xbatch;
 }
 
-template <int NT32, bool CAUSAL, int TC, int NW = 4, bool STAMP = false>   // keys padded to NT32 * 32; NW waves per workgroup
+// NTLOAD (round 4, the default): the q | k | v rows are read ONCE per launch (K / V by the one workgroup of their head, a Q row by one wave),
+// so they are loaded non-temporally and do not displace the attention output -- which the out-proj GEMM reads next -- from L2 / Infinity
+// Cache: vision launch 147.2 -> 144.6 us alone, 4.50 -> 4.43 ms per step in the chain, bit-identical (tools/bench_attention_ab.py 0:0,0:7).
+template <bool NT>
+__device__ __forceinline__ bf16x8 load_q8(const bf16_t* p) {
+    if constexpr (NT) return __builtin_nontemporal_load((const bf16x8*)p);
+    else return *(const bf16x8*)p;
+}
+
+template <int NT32, bool CAUSAL, int TC, int NW = 4, bool STAMP = false, int NTLOAD = 1>   // keys padded to NT32 * 32; NW waves per workgroup; NTLOAD: 0 plain loads, 1 = K / V non-temporal, 2 = Q too
 __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            int T_rt, int width, int xbatch, const int* __restrict__ row_start) {
     constexpr int TP = NT32 * 32;
@@ -92,7 +101,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
         const int q0 = wid * 16 + lrow;
         const int qc = q0 < T ? q0 : T - 1;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) qn[kk] = *(const bf16x8*)(base + (size_t)qc * ld + kk * 32 + lq * 8);
+        for (int kk = 0; kk < 2; ++kk) qn[kk] = load_q8<(NTLOAD >= 2)>(base + (size_t)qc * ld + kk * 32 + lq * 8);
     }
     // stage K and V: ALL global loads of both matrices in flight together (one latency, not two), then the swizzled
     // LDS writes.  (PMC: with K-then-V staging the waves sat 56 % of their life in s_waitcnt.)
@@ -105,9 +114,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
             // branch-free: pad rows load the last valid row and are zeroed by a select at the LDS write (a conditional
             // load, or a select right here, makes hipcc wait for the loads in the middle of the batch)
             const int rc = row < T ? row : T - 1;
-            kv[i] = *(const uint4*)(base + (size_t)rc * ld + width + c * 8);
-            vv[i] = *(const uint4*)(base + (size_t)rc * ld + 2 * width + c * 8);
-
+            if constexpr (NTLOAD >= 1) {
+                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                const u32x4_ a_ = __builtin_nontemporal_load((const u32x4_*)(base + (size_t)rc * ld + width + c * 8));
+                const u32x4_ b_ = __builtin_nontemporal_load((const u32x4_*)(base + (size_t)rc * ld + 2 * width + c * 8));
+                kv[i] = make_uint4(a_.x, a_.y, a_.z, a_.w);
+                vv[i] = make_uint4(b_.x, b_.y, b_.z, b_.w);
+            } else {
+                kv[i] = *(const uint4*)(base + (size_t)rc * ld + width + c * 8);
+                vv[i] = *(const uint4*)(base + (size_t)rc * ld + 2 * width + c * 8);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -133,7 +149,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
             const int q2 = q + NW * 16;
             const int qc = q2 < T ? q2 : T - 1;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) qn[kk] = *(const bf16x8*)(base + (size_t)qc * ld + kk * 32 + lq * 8);
+            for (int kk = 0; kk < 2; ++kk) qn[kk] = load_q8<(NTLOAD >= 2)>(base + (size_t)qc * ld + kk * 32 + lq * 8);
         }
 
         // S^T tiles in groups of G key tiles, K fragments double-buffered in registers: the reads of group g+1 are in
@@ -294,6 +310,8 @@ static int launch_nt(const bf16_t* qkv, bf16_t* out, int batch, int t, int width
 #ifdef KEMR_AB_VARIANTS
         if (g_attn_v != 0) return launch_attention_ab(g_attn_v, g_attn_waves, qkv, out, batch, width, xbatch, stream);
         if (g_attn_waves == 6) { kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, NT32 == 9 ? 6 : 4>; threads = 384; }
+        else if (g_attn_waves == 7) kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, 4, false, NT32 == 9 ? 0 : 1>;      // A/B: the plain (temporal) loads of rounds 1-3
+        else if (g_attn_waves == 5) kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, 4, false, NT32 == 9 ? 2 : 1>;      // A/B: Q rows non-temporal as well
         else if (g_attn_waves == 2 && xbatch) kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, 4, NT32 == 9>;   // stamps: the caller's
                                                                                                                          // `out` has room behind it
         else

@@ -21,6 +21,45 @@ __device__ __forceinline__ float4 load_row4(const f24_t* r, int i, int W) {
     return make_float4(f24_to_f32((bf16_t)(h.x & 0xffff), (uint8_t)l), f24_to_f32((bf16_t)(h.x >> 16), (uint8_t)(l >> 8)),
                        f24_to_f32((bf16_t)(h.y & 0xffff), (uint8_t)(l >> 16)), f24_to_f32((bf16_t)(h.y >> 16), (uint8_t)(l >> 24)));
 }
+// A/B (round 4): the residual rows by non-temporal loads too
+typedef unsigned u32x2_nt __attribute__((ext_vector_type(2)));
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_row4_nt(const float* r, int i, int) {
+    const f32x4_nt v = __builtin_nontemporal_load((const f32x4_nt*)r + i);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 load_row4_nt(const f24_t* r, int i, int W) {
+    const u32x2_nt h = __builtin_nontemporal_load((const u32x2_nt*)r + i);
+    const uint32_t l = __builtin_nontemporal_load((const uint32_t*)((const uint8_t*)r + 2 * (size_t)W) + i);
+    return make_float4(f24_to_f32((bf16_t)(h.x & 0xffff), (uint8_t)l), f24_to_f32((bf16_t)(h.x >> 16), (uint8_t)(l >> 8)),
+                       f24_to_f32((bf16_t)(h.y & 0xffff), (uint8_t)(l >> 16)), f24_to_f32((bf16_t)(h.y >> 16), (uint8_t)(l >> 24)));
+}
+__device__ __forceinline__ float4 load_row4_nt(const bf16_t* r, int i, int) {
+    const u32x2_nt d = __builtin_nontemporal_load((const u32x2_nt*)r + i);
+    return make_float4(bf16_to_f32((bf16_t)(d.x & 0xffff)), bf16_to_f32((bf16_t)(d.x >> 16)),
+                       bf16_to_f32((bf16_t)(d.y & 0xffff)), bf16_to_f32((bf16_t)(d.y >> 16)));
+}
+__device__ __forceinline__ void store_row4_nt(float* r, int i, float4 v, int) {
+    f32x4_nt t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, (f32x4_nt*)r + i);
+}
+__device__ __forceinline__ void store_row4_nt(f24_t* r, int i, float4 v, int W) {
+    const uint32_t a = f32_to_f24_bits(v.x), b = f32_to_f24_bits(v.y), c = f32_to_f24_bits(v.z), d = f32_to_f24_bits(v.w);
+    u32x2_nt h = {(a >> 16) | (b & 0xffff0000u), (c >> 16) | (d & 0xffff0000u)};
+    __builtin_nontemporal_store(h, (u32x2_nt*)r + i);
+    __builtin_nontemporal_store(((a >> 8) & 0xff) | (b & 0xff00) | ((c << 8) & 0xff0000) | ((d << 16) & 0xff000000u), (uint32_t*)((uint8_t*)r + 2 * (size_t)W) + i);
+}
+__device__ __forceinline__ void store_row4_nt(bf16_t* r, int i, float4 v, int) {
+    u32x2_nt pk = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+    __builtin_nontemporal_store(pk, (u32x2_nt*)r + i);
+}
+// the deltas (out-proj / fc2 outputs) are read exactly once, by the LayerNorm that applies them: a non-temporal load
+__device__ __forceinline__ float4 load_delta4(const bf16_t* r, int i) {
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    const u32x2_ d = __builtin_nontemporal_load((const u32x2_*)r + i);
+    return make_float4(bf16_to_f32((bf16_t)(d.x & 0xffff)), bf16_to_f32((bf16_t)(d.x >> 16)),
+                       bf16_to_f32((bf16_t)(d.y & 0xffff)), bf16_to_f32((bf16_t)(d.y >> 16)));
+}
 __device__ __forceinline__ float4 load_row4(const bf16_t* r, int i, int) {
     const uint2 d = ((const uint2*)r)[i];
     return make_float4(bf16_to_f32((bf16_t)(d.x & 0xffff)), bf16_to_f32((bf16_t)(d.x >> 16)),
@@ -53,7 +92,15 @@ __device__ __forceinline__ void store_row4(fp8_t* r, int i, float4 v, int) {
     ((int*)r)[i] = pk;
 }
 
-template <int NV, typename XT, typename OutT, int MODE>   // width = NV * 256
+// NTD (round 4; 3 = the product kernel): cache hints for bytes that are touched exactly once here.  The deltas are dead after this read; the
+// residual row is next read a millisecond and 1.5 GB of traffic later; as ordinary loads / stores they pushed what IS reused soon -- the
+// GEMM operand h this kernel writes, the q | k | v rows the next kernels produce -- out of L2 / Infinity Cache.  Measured in the chain,
+// interleaved A/B rounds of 40 steps on one box, bit-identical results (debug switch ln_nt in A/B builds; profiles/r04_cache_hints.txt):
+//   0 plain loads and stores (rounds 1-3)        18 298 items/s   LayerNorm 5.59 ms   GEMM 31.75   attention 4.15
+//   1 deltas non-temporal                        18 360           5.44                31.70        4.18
+//   2 + residual rows loaded non-temporally      18 439           5.42                31.57        4.18
+//   3 + the ln_1 write-back of x non-temporal    + 0.2 % over 2   5.48                31.35        4.04
+template <int NV, typename XT, typename OutT, int MODE, int NTD = 3>   // width = NV * 256
 __global__ __launch_bounds__(256) void layernorm_kernel(XT* x, const bf16_t* __restrict__ delta, const bf16_t* __restrict__ delta2,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         OutT* y, int rows, float eps) {
@@ -66,15 +113,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(XT* x, const bf16_t* __r
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        v[i] = load_row4(xr, i * 64 + lane, W);
+        v[i] = NTD >= 2 ? load_row4_nt(xr, i * 64 + lane, W) : load_row4(xr, i * 64 + lane, W);
         if constexpr (MODE != 0) {
-            const float4 d = load_row4(delta + (size_t)row * W, i * 64 + lane, W);
+            const float4 d = NTD >= 1 ? load_delta4(delta + (size_t)row * W, i * 64 + lane) : load_row4(delta + (size_t)row * W, i * 64 + lane, W);
             v[i].x += d.x; v[i].y += d.y; v[i].z += d.z; v[i].w += d.w;
             if (MODE == 1 && delta2) {               // wave-uniform
-                const float4 e = load_row4(delta2 + (size_t)row * W, i * 64 + lane, W);
+                const float4 e = NTD >= 1 ? load_delta4(delta2 + (size_t)row * W, i * 64 + lane) : load_row4(delta2 + (size_t)row * W, i * 64 + lane, W);
                 v[i].x += e.x; v[i].y += e.y; v[i].z += e.z; v[i].w += e.w;
             }
-            if constexpr (MODE == 1) store_row4(xr, i * 64 + lane, v[i], W);   // a bf16 stream rounds here; the statistics use the fp32 sum
+            if constexpr (MODE == 1) {                 // a bf16 stream rounds here; the statistics use the fp32 sum
+                if constexpr (NTD >= 3) store_row4_nt(xr, i * 64 + lane, v[i], W);
+                else store_row4(xr, i * 64 + lane, v[i], W);
+            }
         }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
@@ -99,6 +149,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(XT* x, const bf16_t* __r
     }
 }
 
+int g_ln_nt = 3;          // A/B builds: 0 / 1 / 2 = the earlier hint levels (see NTD above)
+
 template <int NV, typename XT>
 static int launch_nv(XT* x, const bf16_t* d1, const bf16_t* d2, int writeback, const float* g, const float* b, void* y, int rows,
                      int out_dtype, hipStream_t s) {
@@ -110,6 +162,18 @@ static int launch_nv(XT* x, const bf16_t* d1, const bf16_t* d2, int writeback, c
         hipLaunchKernelGGL((layernorm_kernel<NV, XT, fp8_t, 2>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (fp8_t*)y, rows, 1e-5f);
     else if (out_dtype == KEMR_FP8)
         hipLaunchKernelGGL((layernorm_kernel<NV, XT, fp8_t, 0>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (fp8_t*)y, rows, 1e-5f);
+#ifdef KEMR_AB_VARIANTS
+    else if (d1 && writeback && g_ln_nt == 0)
+        hipLaunchKernelGGL((layernorm_kernel<NV, XT, bf16_t, 1, 0>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (bf16_t*)y, rows, 1e-5f);
+    else if (d1 && g_ln_nt == 0)
+        hipLaunchKernelGGL((layernorm_kernel<NV, XT, bf16_t, 2, 0>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (bf16_t*)y, rows, 1e-5f);
+    else if (d1 && writeback && g_ln_nt == 1)
+        hipLaunchKernelGGL((layernorm_kernel<NV, XT, bf16_t, 1, 1>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (bf16_t*)y, rows, 1e-5f);
+    else if (d1 && g_ln_nt == 1)
+        hipLaunchKernelGGL((layernorm_kernel<NV, XT, bf16_t, 2, 1>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (bf16_t*)y, rows, 1e-5f);
+    else if (d1 && writeback && g_ln_nt == 2)
+        hipLaunchKernelGGL((layernorm_kernel<NV, XT, bf16_t, 1, 2>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (bf16_t*)y, rows, 1e-5f);
+#endif
     else if (d1 && writeback)
         hipLaunchKernelGGL((layernorm_kernel<NV, XT, bf16_t, 1>), dim3(blocks), dim3(256), 0, s, x, d1, d2, g, b, (bf16_t*)y, rows, 1e-5f);
     else if (d1)

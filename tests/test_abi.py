@@ -61,7 +61,7 @@ def test_model_options_and_debug_switches_are_separate():
     lib.kemr_model_destroy(h1)
     lib.kemr_model_destroy(h2)
     before = {k: debug.get(k) for k in debug.KEYS}
-    assert before["gemm_variant"] == 0 and before["gemm_kl"] == 0 and before["sim_lists"] == 1
+    assert before["gemm_variant"] == 0 and before["gemm_kl"] == 0 and before["sim_lists"] == 1 and before["ln_nt"] == 3
     with debug.override(gemm_order=0, gemm_variant=2):
         assert debug.get("gemm_order") == 0 and debug.get("gemm_variant") == 2 and debug.get("gemm_conc") == before["gemm_conc"]
         debug.set_gemm_variant(7 | (1 << 16))                     # the packed form touches variant and flags (and what else is non-zero) only ...
@@ -82,10 +82,10 @@ def test_product_library_refuses_the_experiment_kernels():
     if debug.ab_variants():
         pytest.skip("this libkemr.so was built with --ab-variants")
     for key, value in (("attn_v", 1), ("attn_v", 4), ("attn_waves", 6), ("gemm_kl", 1), ("gemm_variant", 3), ("gemm_variant", 4),
-                       ("gemm_variant", 9), ("gemm_flags", 64)):
+                       ("gemm_variant", 9), ("gemm_flags", 64), ("ln_nt", 0)):
         with pytest.raises(RuntimeError, match="A/B experiment kernel"):
             debug.set(key, value)
-        assert debug.get(key) == 0
+        assert debug.get(key) == (3 if key == "ln_nt" else 0)
     for key, value in (("gemm_variant", 1), ("gemm_variant", 2), ("gemm_variant", 7), ("gemm_variant", 8), ("attn_xcd", 0), ("sim_lists", 3)):
         with debug.override(**{key: value}):
             assert debug.get(key) == value
