@@ -114,6 +114,73 @@ def test_bpe_tokenizer_with_a_small_merge_table(tmp_path):
     assert tok.encode("abc de") == [tok.encoder["abc</w>"], tok.encoder["de</w>"]]
 
 
+def test_bpe_algorithm_against_an_independent_engine(tmp_path):
+    """Row a3 (clip.tokenize; /root/reference/src/clip/eval/evaluator.py:126,132).  The vocabulary file cannot be fetched here, so OpenAI's ids
+    stay unpinned -- but the ALGORITHM need not: the same synthetic merge table (a small BPE trained below over CLIP's symbol alphabet, written
+    in bpe_simple_vocab's format) goes into this build's BPETokenizer and into the HuggingFace `tokenizers` BPE engine (Rust; what the
+    reference's evaluator_hf path tokenises with), set up the way CLIP's published tokenizer.json is: NFC + whitespace collapse + lowercase,
+    the same split regex, byte-level symbols, '</w>' end-of-word suffix.  Ids must agree on ASCII, apostrophes, digits, punctuation runs,
+    accents, unknown words and non-Latin scripts."""
+    import collections
+    import gzip
+    import random
+    tk_mod = pytest.importorskip("tokenizers")
+    from tokenizers import Regex, Tokenizer, models, normalizers, pre_tokenizers
+    be = tokenizer.bytes_to_unicode()
+
+    def train(words, n_merges):
+        vocab = collections.Counter()
+        for w in words:
+            sym = [be[b] for b in w.encode("utf-8")]
+            sym[-1] += "</w>"
+            vocab[tuple(sym)] += 1
+        merges = []
+        for _ in range(n_merges):
+            pairs = collections.Counter()
+            for sym, c in vocab.items():
+                for x, y in zip(sym[:-1], sym[1:]):
+                    pairs[(x, y)] += c
+            if not pairs:
+                break
+            best = max(sorted(pairs), key=lambda q: pairs[q])
+            merges.append(best)
+            new = collections.Counter()
+            for sym, c in vocab.items():
+                out, i = [], 0
+                while i < len(sym):
+                    if i + 1 < len(sym) and (sym[i], sym[i + 1]) == best:
+                        out.append(sym[i] + sym[i + 1])
+                        i += 2
+                    else:
+                        out.append(sym[i])
+                        i += 1
+                new[tuple(out)] += c
+            vocab = new
+        return merges
+
+    rng = random.Random(0)
+    base = ("amphora vase bronze marble portrait landscape oil canvas roman greek medieval baroque gilded wooden panel statue relief fresco "
+            "mosaic coin sword helmet textile manuscript folio saint king queen river harbour café naïve 1234 it's don't über señor façade").split()
+    merges = train([rng.choice(base) for _ in range(400)] + base, 250)
+    path = tmp_path / "bpe_small.txt.gz"
+    with gzip.open(path, "wt", encoding="utf-8") as f:
+        f.write("\n".join(["#version: test"] + [" ".join(m) for m in merges]))
+    mine = tokenizer.BPETokenizer(str(path))
+    assert len(merges) >= 100 and len(mine.encoder) == 512 + len(merges) + 2      # (the word list is fully merged before 250 merges)
+    other = Tokenizer(models.BPE(vocab=dict(mine.encoder), merges=[tuple(m) for m in merges], unk_token="<|endoftext|>",
+                                 continuing_subword_prefix="", end_of_word_suffix="</w>", fuse_unk=False))
+    other.normalizer = normalizers.Sequence([normalizers.NFC(), normalizers.Replace(Regex(r"\s+"), " "), normalizers.Lowercase()])
+    other.pre_tokenizer = pre_tokenizers.Sequence([
+        pre_tokenizers.Split(Regex(r"""'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+"""), behavior="removed", invert=True),
+        pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=False)])
+    texts = ["a bronze statue", "Roman  marble PORTRAIT, gilded!", "it's a café façade", "1234 coins & 56 swords", "naïve über señor",
+             "medieval manuscript folio 12", "don't", "  leading and trailing  ", "unknownword xyzzy", "mosaic-fresco/relief", "Ünïcödé ΣΩ 漢字",
+             "we're they'll I'd you've", "a\tb\nc", "!!! ??? ...", ""] + [" ".join(rng.choice(base) for _ in range(12)) for _ in range(20)]
+    for t in texts:
+        assert mine.encode(t) == other.encode(t.strip(), add_special_tokens=False).ids, t
+    assert tk_mod is not None
+
+
 def test_preprocess_matches_recipe():
     from PIL import Image
     from knowledge_enhanced_multimodal_retrieval_amd.preprocess import CLIP_MEAN, CLIP_STD, ClipPreprocess
