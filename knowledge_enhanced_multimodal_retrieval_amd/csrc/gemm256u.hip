@@ -78,13 +78,28 @@ __device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
 
 template <int I> struct HookAt { static constexpr int value = I; };
 
+// Wave priority around the MFMA clusters (compile-time, -DKEMR_GEMM_PRIO=n for tools/ab_build_flag.sh; a run-time switch inside the K loop
+// costs 5-8 %).  1 = NO priority changes: the product kernel since round 4.  0 = priority 1 for the cluster, 0 for the load interval
+// (rounds 1-3: the computing wave then starves its SIMD partner's load interval of issue slots exactly where the LDS-DMA pieces, at
+// 60-100 issue cycles each, are the long pole); 2 = static, the second-dispatched wave half (waves 4-7) at priority 1 for the whole
+// launch (cdna guide T5, static form); 3 = the inverse of 0 (the LOAD interval at priority 1); 4 = static for waves 0-3.
+// Same box, interleaved builds, bench.py --steps 40 (profiles/r04_gemm_prio.txt): mode 0 GEMM class 31.82 ms per step (0.5255 of peak),
+// mode 2 31.24 (0.5355), mode 1 31.14 (0.5371): +1.55 % on the step.  Results do not depend on the mode.
+#ifndef KEMR_GEMM_PRIO
+#define KEMR_GEMM_PRIO 1
+#endif
+__device__ __forceinline__ void cluster_prio(int v) {
+    if constexpr (KEMR_GEMM_PRIO == 0) { if (v) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+    if constexpr (KEMR_GEMM_PRIO == 3) { if (v) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+}
+
 // 16 MFMAs: rows MH*64 .. +63 of the wave's tile x its 64 columns x one 32-wide k step.  FIRST: the accumulators' first
 // product of a tile, C = the bias quad of the column group (a lane's acc[mi][ni] covers columns ni*16 + lq*4 .. +3 for every
 // mi).  hook(HookAt<i>) runs after the i-th MFMA: a few scalar instructions issue for free while the matrix pipe is busy.
 template <int MH, bool FIRST, class Hook>
 __device__ __forceinline__ void cluster(f32x4 (&acc)[8][4], const bf16x8 (&af)[4], const bf16x8 (&wf)[4], const u32x4 (&b4)[4],
                                         Hook&& hook) {
-    __builtin_amdgcn_s_setprio(1);
+    cluster_prio(1);
     asm volatile("s_nop 1" ::: "memory");      // any compiler VALU write just above -> first asm MFMA operand read
     auto step = [&](auto mi_c, auto ni_c) {
         constexpr int mi = decltype(mi_c)::value, ni = decltype(ni_c)::value;
@@ -102,7 +117,7 @@ __device__ __forceinline__ void cluster(f32x4 (&acc)[8][4], const bf16x8 (&af)[4
     step(I1{}, I0{}); step(I1{}, I1{}); step(I1{}, I2{}); step(I1{}, I3{});
     step(I2{}, I0{}); step(I2{}, I1{}); step(I2{}, I2{}); step(I2{}, I3{});
     step(I3{}, I0{}); step(I3{}, I1{}); step(I3{}, I2{}); step(I3{}, I3{});
-    __builtin_amdgcn_s_setprio(0);
+    cluster_prio(0);
     // the fragment reads the hooks issued (asm ds_read: hipcc does not count them) have returned before the wave arrives at the
     // barrier behind this cluster: that orders them in front of any re-staging of the region and in front of their use
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -115,7 +130,7 @@ __device__ __forceinline__ void cluster(f32x4 (&acc)[8][4], const bf16x8 (&af)[4
 template <bool FIRST, class Hook>
 __device__ __forceinline__ void cluster32(f32x4 (&acc)[8][4], const bf16x8 (&af)[8], const bf16x8 (&wf)[4], const u32x4 (&b4)[4],
                                           Hook&& hook) {
-    __builtin_amdgcn_s_setprio(1);
+    cluster_prio(1);
     asm volatile("s_nop 1" ::: "memory");      // any compiler VALU write just above -> first asm MFMA operand read
     auto step = [&](auto mi_c, auto ni_c) {
         constexpr int mi = decltype(mi_c)::value, ni = decltype(ni_c)::value;
@@ -135,7 +150,7 @@ __device__ __forceinline__ void cluster32(f32x4 (&acc)[8][4], const bf16x8 (&af)
     row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{}); row(std::integral_constant<int, 2>{});
     row(std::integral_constant<int, 3>{}); row(std::integral_constant<int, 4>{}); row(std::integral_constant<int, 5>{});
     row(std::integral_constant<int, 6>{}); row(std::integral_constant<int, 7>{});
-    __builtin_amdgcn_s_setprio(0);
+    cluster_prio(0);
 }
 
 // fp8 (OCP e4m3) operands: one block-scaled MFMA covers K = 128 (a lane holds 32 consecutive k bytes of its row), at twice
@@ -146,7 +161,7 @@ typedef __attribute__((ext_vector_type(8))) int fp8x32;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 template <int MH, int NH, bool FIRST, class Hook>
 __device__ __forceinline__ void quad8(f32x4 (&acc)[8][4], const fp8x32 (&af)[4], const fp8x32 (&wf)[2], int one, Hook&& hook) {
-    __builtin_amdgcn_s_setprio(1);
+    cluster_prio(1);
     asm volatile("s_nop 1" ::: "memory");
     auto step = [&](auto mi_c, auto ni_c) {
         constexpr int mi = decltype(mi_c)::value, ni = decltype(ni_c)::value;
@@ -163,7 +178,7 @@ __device__ __forceinline__ void quad8(f32x4 (&acc)[8][4], const fp8x32 (&af)[4],
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     step(I0{}, I0{}); step(I0{}, I1{}); step(I1{}, I0{}); step(I1{}, I1{});
     step(I2{}, I0{}); step(I2{}, I1{}); step(I3{}, I0{}); step(I3{}, I1{});
-    __builtin_amdgcn_s_setprio(0);
+    cluster_prio(0);
 }
 
 }  // namespace
@@ -203,6 +218,8 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
+    if constexpr (KEMR_GEMM_PRIO == 2) { if (wid >= 4) __builtin_amdgcn_s_setprio(1); }      // (wid is wave-uniform: readfirstlane above)
+    if constexpr (KEMR_GEMM_PRIO == 4) { if (wid < 4) __builtin_amdgcn_s_setprio(1); }
 
     const int tiles_n = p.N >> 8;
     const int tiles_m = (p.M + 255) >> 8;
