@@ -85,6 +85,9 @@ template <int I> struct HookAt { static constexpr int value = I; };
 // launch (cdna guide T5, static form); 3 = the inverse of 0 (the LOAD interval at priority 1); 4 = static for waves 0-3.
 // Same box, interleaved builds, bench.py --steps 40 (profiles/r04_gemm_prio.txt): mode 0 GEMM class 31.82 ms per step (0.5255 of peak),
 // mode 2 31.24 (0.5355), mode 1 31.14 (0.5371): +1.55 % on the step.  Results do not depend on the mode.
+#ifndef KEMR_GEMM_MID
+#define KEMR_GEMM_MID 1        // K-tiles that cannot wrap a stream advance it by plain adds (0: the wrap arithmetic everywhere, rounds 2-3)
+#endif
 #ifndef KEMR_GEMM_PRIO
 #define KEMR_GEMM_PRIO 1
 #endif
@@ -522,6 +525,19 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
         if constexpr (J == 3) { asm volatile("" : "+s"(inc_w)); ow = tw == nt ? toff_w : inc_w; asm volatile("" : "+s"(ow)); }
         if constexpr (J == 4) { asm volatile("" : "+s"(ow)); ow1 = ow + w_half; asm volatile("" : "+s"(ow1)); }
     };
+    // The same advances for a K-tile in which neither stream can reach the end of its tile (1 <= t < nt - 3, see the tile loop):
+    // a count-down and an add per offset, 5 scalar instructions per K-tile instead of 17 and no v_readlane.
+    auto step_a_mid = [&ta, &oa](auto at) {
+        constexpr int J = decltype(at)::value;
+        if constexpr (J == 0) { asm volatile("s_sub_i32 %0, %0, 1" : "+s"(ta) :: "scc"); }
+        if constexpr (J == 1) { asm volatile("s_add_u32 %0, %0, 0x80" : "+s"(oa) :: "scc"); }
+    };
+    auto step_w_mid = [&tw, &ow, &ow1](auto at) {
+        constexpr int J = decltype(at)::value;
+        if constexpr (J == 0) { asm volatile("s_sub_i32 %0, %0, 1" : "+s"(tw) :: "scc"); }
+        if constexpr (J == 1) { asm volatile("s_add_u32 %0, %0, 0x80" : "+s"(ow) :: "scc"); }
+        if constexpr (J == 2) { asm volatile("s_add_u32 %0, %0, 0x80" : "+s"(ow1) :: "scc"); }
+    };
     auto nohook = [](auto) {};
     // every cluster reads the NEXT cluster's fragments (their registers were last used two clusters ago)
     auto hook_m1 = [&wk1, &ak1, &vb1, &va1](auto at) {                  // M1 (lo rows, k 0-31) -> M2's fragments: W and lo rows, k 32-63
@@ -549,6 +565,21 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
         else if constexpr (I < 8) { KEMR_DSR(ak0[I - 4], va0, (I - 4) * 2048); }
         else if constexpr (I == 8) step_w(HookAt<0>{});
         else if constexpr (I >= 10 && I <= 13) step_w(HookAt<I - 9>{});
+        else if constexpr (I == 15) { asm volatile("" : "+s"(gpar)); gpar ^= 1; asm volatile("" : "+s"(gpar)); }
+    };
+    auto hook_m2_mid = [&ak0, &va0, &step_a_mid](auto at) {
+        constexpr int I = decltype(at)::value;
+        if constexpr (I < 4) { KEMR_DSR(ak0[I], va0, 8192 + I * 2048); }
+        else if constexpr (I == 7) step_a_mid(HookAt<0>{});
+        else if constexpr (I == 11) step_a_mid(HookAt<1>{});
+    };
+    auto hook_m4_mid = [&wk0, &ak0, &vb0, &va0, &gpar, &step_w_mid](auto at) {
+        constexpr int I = decltype(at)::value;
+        if constexpr (I < 4) { KEMR_DSR(wk0[I], vb0, I * 2048); }
+        else if constexpr (I < 8) { KEMR_DSR(ak0[I - 4], va0, (I - 4) * 2048); }
+        else if constexpr (I == 9) step_w_mid(HookAt<0>{});
+        else if constexpr (I == 11) step_w_mid(HookAt<1>{});
+        else if constexpr (I == 13) step_w_mid(HookAt<2>{});
         else if constexpr (I == 15) { asm volatile("" : "+s"(gpar)); gpar ^= 1; asm volatile("" : "+s"(gpar)); }
     };
     // LONGK.  MA (k 0-31 of buffer g): reads the k 32-63 fragments of the same buffer -- W into the other register set in the first
@@ -588,12 +619,22 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
         if constexpr (I >= 1 && I <= 9 && (I & 1)) step_w(HookAt<(I - 1) / 2>{});
         else if constexpr (I == 11) { asm volatile("" : "+s"(gpar)); gpar ^= 1; asm volatile("" : "+s"(gpar)); }
     };
+    auto hook8_m2_mid = [&step_a_mid](auto at) { constexpr int I = decltype(at)::value; if constexpr (I == 3) step_a_mid(HookAt<0>{}); else if constexpr (I == 7) step_a_mid(HookAt<1>{}); };
+    auto hook8_m4_mid = [&gpar, &step_w_mid](auto at) {
+        constexpr int I = decltype(at)::value;
+        if constexpr (I == 3) step_w_mid(HookAt<0>{});
+        else if constexpr (I == 5) step_w_mid(HookAt<1>{});
+        else if constexpr (I == 7) step_w_mid(HookAt<2>{});
+        else if constexpr (I == 11) { asm volatile("" : "+s"(gpar)); gpar ^= 1; asm volatile("" : "+s"(gpar)); }
+    };
 
     // One K-tile.  LDS-DMA per interval: L1 A0(g+1), L2 A1(g+1), L3 W0(g+2), L4 W1(g+2) [+ bias]; the wait that needs K-tile
     // g+1 complete sits at the end of M3 (in front of the barrier in front of M4, whose hooks read K-tile g+1) and leaves
     // W0(g+2) in flight.
-    auto ktile = [&](auto first_c) {
+    // MID: a K-tile in which no stream wraps (no bias piece either: that rides with a tile's first W piece).
+    auto ktile = [&](auto first_c, auto mid_c) {
         constexpr bool FIRST = decltype(first_c)::value;
+        constexpr bool MID = decltype(mid_c)::value;
         const unsigned buf_this = stage_lds + gpar * PBUF;
         const unsigned abuf_next = buf_lds + (gpar ^ 1) * PBUF;
         if constexpr (FP8) {
@@ -613,7 +654,8 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w18[0]), "+v"(w18[1]) :: "memory");     // the reads are done in front of the barrier: W may be re-staged behind the next one
             __builtin_amdgcn_s_barrier();
             stamp(2);
-            quad8<0, 1, FIRST>(acc, af8, w18, one, hook8_m2);
+            if constexpr (MID) quad8<0, 1, FIRST>(acc, af8, w18, one, hook8_m2_mid);
+            else quad8<0, 1, FIRST>(acc, af8, w18, one, hook8_m2);
             __builtin_amdgcn_s_barrier();
             stamp(3);
             ld_a8(sa + 8192);
@@ -627,10 +669,11 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             stamp(5);
             stage_w(ow1, buf_this + 3 * PHALF);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // the half's own A(g+1) pieces landed; W(g+2) stays in flight
-            stage_bias();
+            if constexpr (!MID) stage_bias();
             __builtin_amdgcn_s_barrier();
             stamp(6);
-            quad8<1, 0, FIRST>(acc, af8, w08, one, hook8_m4);
+            if constexpr (MID) quad8<1, 0, FIRST>(acc, af8, w08, one, hook8_m4_mid);
+            else quad8<1, 0, FIRST>(acc, af8, w08, one, hook8_m4);
             __builtin_amdgcn_s_barrier();
             stamp(7);
         } else if constexpr (LONGK) {
@@ -667,7 +710,8 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             stage_a(1, oa, abuf_next);
             __builtin_amdgcn_s_barrier();
             stamp(2);
-            cluster<0, false>(acc, ak1, wk1, b4, hook_m2);
+            if constexpr (MID) cluster<0, false>(acc, ak1, wk1, b4, hook_m2_mid);
+            else cluster<0, false>(acc, ak1, wk1, b4, hook_m2);
             __builtin_amdgcn_s_barrier();
             stamp(3);
             stage_w(ow, buf_this + 2 * PHALF);
@@ -681,10 +725,11 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             stamp_pre(12);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // the half's own A(g+1) pieces landed; W(g+2) stays in flight
             stamp_pre(13);
-            stage_bias();
+            if constexpr (!MID) stage_bias();
             __builtin_amdgcn_s_barrier();
             stamp(6);
-            cluster<1, false>(acc, ak1, wk1, b4, hook_m4);
+            if constexpr (MID) cluster<1, false>(acc, ak1, wk1, b4, hook_m4_mid);
+            else cluster<1, false>(acc, ak1, wk1, b4, hook_m4);
             __builtin_amdgcn_s_barrier();
             stamp(7);
         }
@@ -725,8 +770,16 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             for (int ni = 0; ni < 4; ++ni) b4[ni] = lds_read_b128(bias_r + ni * 64);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]) :: "memory");
         }
-        ktile(std::true_type{});
-        for (int t = 1; t < nt; ++t) ktile(std::false_type{});
+        // The A stream reaches the end of its tile in K-tile nt - 2 and the W stream in K-tile nt - 3 (t = 0 as well when nt <= 3):
+        // the K-tiles in between advance the streams without the wrap arithmetic.
+        ktile(std::true_type{}, std::false_type{});
+        if constexpr (KEMR_GEMM_MID && !LONGK) {
+            const int t_mid = nt - 3;
+            for (int t = 1; t < t_mid; ++t) ktile(std::false_type{}, std::true_type{});
+            for (int t = t_mid < 1 ? 1 : t_mid; t < nt; ++t) ktile(std::false_type{}, std::false_type{});
+        } else {
+            for (int t = 1; t < nt; ++t) ktile(std::false_type{}, std::false_type{});
+        }
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // asm MFMA result -> VALU read (>= 12 wait states)
 
         if constexpr (SIM != 0) {
