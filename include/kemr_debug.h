@@ -44,7 +44,8 @@ extern "C" {
  *                   the exact fallback forced to run after the lists
  *   "ln_nt"         LayerNorm cache hints: 3 = deltas and residual rows loaded, the ln_1 write-back of x stored non-temporally (the product
  *                   kernel); [A/B] 0 = plain (rounds 1-3), 1 = deltas only, 2 = deltas + row loads
- *   "attn_waves"    also: [A/B] 7 = the vision attention kernel with plain K / V loads (rounds 1-3), 5 = Q rows non-temporal as well
+ *   "attn_waves"    also: [A/B] 7 = the vision attention kernel with plain K / V loads (rounds 1-3), 5 = Q rows non-temporal as well,
+ *                   8 (with attn_v 0) = TIMING ONLY, wrong results: the ragged 17th query tile (one valid row) is not computed
  *   "ab_variants"   read-only: 1 = the library holds the [A/B] kernels */
 int kemr_debug_set(const char* key, int value);
 int kemr_debug_get(const char* key, int* value);

@@ -52,7 +52,7 @@ __device__ __forceinline__ bf16x8 load_q8(const bf16_t* p) {
     else return *(const bf16x8*)p;
 }
 
-template <int NT32, bool CAUSAL, int TC, int NW = 4, bool STAMP = false, int NTLOAD = 1>   // keys padded to NT32 * 32; NW waves per workgroup; NTLOAD: 0 plain loads, 1 = K / V non-temporal, 2 = Q too
+template <int NT32, bool CAUSAL, int TC, int NW = 4, bool STAMP = false, int NTLOAD = 1, bool SKIPTAIL = false>   // keys padded to NT32 * 32; NW waves per workgroup; NTLOAD: 0 plain loads, 1 = K / V non-temporal, 2 = Q too
 __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            int T_rt, int width, int xbatch, const int* __restrict__ row_start) {
     constexpr int TP = NT32 * 32;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
     const int ld = 3 * width;
     const bf16_t* base = qkv + row0 * ld + h * 64;
     const int lrow = lane & 15, lq = lane >> 4;
-    const int nqt = (T + 15) >> 4;
+    const int nqt = SKIPTAIL ? T >> 4 : (T + 15) >> 4;      // SKIPTAIL (A/B timing only, WRONG results): the ragged last query tile is not computed
 
     unsigned long long st_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
     auto stamp = [&](int k) {
@@ -311,6 +311,7 @@ static int launch_nt(const bf16_t* qkv, bf16_t* out, int batch, int t, int width
         if (g_attn_v != 0) return launch_attention_ab(g_attn_v, g_attn_waves, qkv, out, batch, width, xbatch, stream);
         if (g_attn_waves == 6) { kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, NT32 == 9 ? 6 : 4>; threads = 384; }
         else if (g_attn_waves == 7) kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, 4, false, NT32 == 9 ? 0 : 1>;      // A/B: the plain (temporal) loads of rounds 1-3
+        else if (g_attn_waves == 8) kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, 4, false, 1, NT32 == 9>;          // A/B timing only: without the 17th (one-row) query tile
         else if (g_attn_waves == 5) kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, 4, false, NT32 == 9 ? 2 : 1>;      // A/B: Q rows non-temporal as well
         else if (g_attn_waves == 2 && xbatch) kern = attention_kernel<NT32, false, NT32 == 9 ? 257 : 0, 4, NT32 == 9>;   // stamps: the caller's
                                                                                                                          // `out` has room behind it
