@@ -346,7 +346,7 @@ def main():
         "vs_baseline": None, "dtype": {"fp8": "fp8 (QKV) + bf16", "fp8-res16": "fp8 (QKV) + bf16", "fp8-mlp": "fp8 (QKV, fc1) + bf16"}.get(args.precision, "bf16"), "data": "synthetic",
         "config": {"workload": "CLIP ViT-L/14 zero-shot: 43k-gallery encode (1 image + query + target text per item, "
                                "224x224 / 77 tokens) + T2I top-10, BASELINE configs[1]",
-                   "model": args.model, "residual_stream": "bf16" if args.precision.endswith("res16") else ("fp24" if args.precision.endswith("x24") else "fp32"), "batch_per_gpu": B, "text_group": text_group, "gallery": GALLERY, "parallelism": f"dp{world} (gallery sharded)",
+                   "architecture": args.model, "residual_stream": "bf16" if args.precision.endswith("res16") else ("fp24" if args.precision.endswith("x24") else "fp32"), "batch_per_gpu": B, "text_group": text_group, "gallery": GALLERY, "parallelism": f"dp{world} (gallery sharded)",
                    "items_timed": items, "rccl_ranks": rccl_ranks, "backend": (os.environ.get("KEMR_DIST_BACKEND", "nccl") if world > 1 else None),
                    "shard_bounds": shard_bounds},
         "images_per_s": B * world * args.steps / elapsed,
