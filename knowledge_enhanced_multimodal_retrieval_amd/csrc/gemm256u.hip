@@ -85,6 +85,9 @@ template <int I> struct HookAt { static constexpr int value = I; };
 // launch (cdna guide T5, static form); 3 = the inverse of 0 (the LOAD interval at priority 1); 4 = static for waves 0-3.
 // Same box, interleaved builds, bench.py --steps 40 (profiles/r04_gemm_prio.txt): mode 0 GEMM class 31.82 ms per step (0.5255 of peak),
 // mode 2 31.24 (0.5355), mode 1 31.14 (0.5371): +1.55 % on the step.  Results do not depend on the mode.
+#ifndef KEMR_GEMM_SBASE
+#define KEMR_GEMM_SBASE 1
+#endif
 #ifndef KEMR_GEMM_MID
 #define KEMR_GEMM_MID 1        // K-tiles that cannot wrap a stream advance it by plain adds (0: the wrap arithmetic everywhere, rounds 2-3)
 #endif
@@ -364,15 +367,29 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     const unsigned stage_lds = lds_addr(smem) + wid * 2048;        // W pieces: + region; A pieces use a_dst from the buffer base
     const unsigned buf_lds = lds_addr(smem);
     const unsigned a_dst = (unsigned)(wr * PHALF + (wid & 3) * 4096);      // the wave's 32 rows inside its half's region
+    // KEMR_GEMM_SBASE (round 4): the stream offset goes into the SCALAR base (two SALU per call) instead of into each piece's lane
+    // offset (one VALU per piece): the load interval then issues no vector-ALU instruction beside its partner's MFMA cluster.
     auto stage_a = [&](int pair, unsigned off, unsigned buf) {             // pair 0 / 1: rows 0-15 / 16-31 of the wave's 32
-        const unsigned v0 = a_lane[2 * pair] + off, v1 = a_lane[2 * pair + 1] + off;
-        KEMR_GLDS(v0, p.A, buf + a_dst + pair * 2048);
-        KEMR_GLDS(v1, p.A, buf + a_dst + pair * 2048 + 1024);
+        if constexpr (KEMR_GEMM_SBASE) {
+            const char* const sb = (const char*)p.A + off;
+            KEMR_GLDS(a_lane[2 * pair], sb, buf + a_dst + pair * 2048);
+            KEMR_GLDS(a_lane[2 * pair + 1], sb, buf + a_dst + pair * 2048 + 1024);
+        } else {
+            const unsigned v0 = a_lane[2 * pair] + off, v1 = a_lane[2 * pair + 1] + off;
+            KEMR_GLDS(v0, p.A, buf + a_dst + pair * 2048);
+            KEMR_GLDS(v1, p.A, buf + a_dst + pair * 2048 + 1024);
+        }
     };
     auto stage_w = [&](unsigned off, unsigned dst) {
-        const unsigned v0 = w_lane0 + off, v1 = w_lane1 + off;
-        KEMR_GLDS(v0, p.W, dst);
-        KEMR_GLDS(v1, p.W, dst + 1024);
+        if constexpr (KEMR_GEMM_SBASE) {
+            const char* const sb = (const char*)p.W + off;
+            KEMR_GLDS(w_lane0, sb, dst);
+            KEMR_GLDS(w_lane1, sb, dst + 1024);
+        } else {
+            const unsigned v0 = w_lane0 + off, v1 = w_lane1 + off;
+            KEMR_GLDS(v0, p.W, dst);
+            KEMR_GLDS(v1, p.W, dst + 1024);
+        }
     };
     // With the W1 half of K-tile 0 of a tile: that tile's bias (wave 0).  The bias rides with the LAST piece in front of a
     // wait-free stretch, so that nobody waits for it straight after issuing it.
