@@ -85,6 +85,9 @@ template <int I> struct HookAt { static constexpr int value = I; };
 // launch (cdna guide T5, static form); 3 = the inverse of 0 (the LOAD interval at priority 1); 4 = static for waves 0-3.
 // Same box, interleaved builds, bench.py --steps 40 (profiles/r04_gemm_prio.txt): mode 0 GEMM class 31.82 ms per step (0.5255 of peak),
 // mode 2 31.24 (0.5355), mode 1 31.14 (0.5371): +1.55 % on the step.  Results do not depend on the mode.
+#ifndef KEMR_GEMM_FLIPASM
+#define KEMR_GEMM_FLIPASM 1
+#endif
 #ifndef KEMR_GEMM_SBASE
 #define KEMR_GEMM_SBASE 1
 #endif
@@ -569,11 +572,14 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     };
     auto hook_m3 = [&ak1, &vb0, &vb1, &va0, &va1](auto at) {            // M3 -> M4's fragments: hi rows, k 32-63; then the bases switch buffer
         constexpr int I = decltype(at)::value;
+        // (the flips as asm: as C++ the compiler hoists two of them into the wave's LOAD interval, where a vector-ALU instruction costs
+        // the partner's MFMA cluster issue slots)
         if constexpr (I < 4) { KEMR_DSR(ak1[I], va1, 8192 + I * 2048); }
-        else if constexpr (I == 6) { vb0 ^= PBUF; asm volatile("" : "+v"(vb0)); }
-        else if constexpr (I == 8) { vb1 ^= PBUF; asm volatile("" : "+v"(vb1)); }
-        else if constexpr (I == 10) { va0 ^= PBUF; asm volatile("" : "+v"(va0)); }
-        else if constexpr (I == 12) { va1 ^= PBUF; asm volatile("" : "+v"(va1)); }
+        else if constexpr (I == 6) { if constexpr (KEMR_GEMM_FLIPASM) asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(vb0)); else { vb0 ^= PBUF; asm volatile("" : "+v"(vb0)); } }
+        else if constexpr (I == 8) { if constexpr (KEMR_GEMM_FLIPASM) asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(vb1)); else { vb1 ^= PBUF; asm volatile("" : "+v"(vb1)); } }
+        else if constexpr (I == 10) { if constexpr (KEMR_GEMM_FLIPASM) asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(va0)); else { va0 ^= PBUF; asm volatile("" : "+v"(va0)); } }
+        else if constexpr (I == 12) { if constexpr (KEMR_GEMM_FLIPASM) asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(va1)); else { va1 ^= PBUF; asm volatile("" : "+v"(va1)); } }
+        static_assert(PBUF == 0x10000, "the asm flips above");
     };
     // M4 -> the next K-tile's M1 fragments: W and lo rows, k 0-31; W stream (both of its offsets were last used in L4)
     auto hook_m4 = [&wk0, &ak0, &vb0, &va0, &gpar, &step_w](auto at) {
