@@ -85,6 +85,9 @@ template <int I> struct HookAt { static constexpr int value = I; };
 // launch (cdna guide T5, static form); 3 = the inverse of 0 (the LOAD interval at priority 1); 4 = static for waves 0-3.
 // Same box, interleaved builds, bench.py --steps 40 (profiles/r04_gemm_prio.txt): mode 0 GEMM class 31.82 ms per step (0.5255 of peak),
 // mode 2 31.24 (0.5355), mode 1 31.14 (0.5371): +1.55 % on the step.  Results do not depend on the mode.
+#ifndef KEMR_GEMM_STORE_MIX
+#define KEMR_GEMM_STORE_MIX 0      // C stores: 0 = all non-temporal (the product), 3 = every other 16-row pass as plain write-back stores, 4 = all plain (A/B)
+#endif
 #ifndef KEMR_GEMM_FLIPASM
 #define KEMR_GEMM_FLIPASM 1
 #endif
@@ -1049,12 +1052,13 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
                     D1 = add8(D1, xr1[(P) & 3]);                                                                                    \
                 }                                                                                                                   \
             } while (0)
-    #define KEMR_STORE_PASS(D0, D1, WAIT)                                                                                           \
+    #define KEMR_STORE_PASS(D0, D1, WAIT) KEMR_STORE_PASS_(D0, D1, WAIT, 0)
+    #define KEMR_STORE_PASS_(D0, D1, WAIT, ODD)                                                                                     \
             do {                                                                                                                    \
                 asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" : "+v"(D0), "+v"(D1) :: "memory");                                      \
                 const unsigned voff8 = voff + step8;                                                                                \
                 if (!DBG || !(p.dbg & 1)) {                                                                                         \
-                    if (DBG && (p.dbg & 4))                                                                                         \
+                    if ((DBG && (p.dbg & 4)) || (KEMR_GEMM_STORE_MIX == 3 && (ODD)) || KEMR_GEMM_STORE_MIX == 4)                     \
                         asm volatile("global_store_dwordx4 %0, %1, %4\n\tglobal_store_dwordx4 %2, %3, %4\n\ts_nop 1"               \
                                      :: "v"(voff), "v"(D0), "v"(voff8), "v"(D1), "s"(ctile) : "memory");                            \
                     else                                                                                                            \
@@ -1067,14 +1071,14 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
                 // one area: a pass's read-back must have landed before the next pass's writes (the wait of its stores covers it);
                 // the next pass's conversion (and QuickGELU) is issued in front of that wait
                 pack(acc[0]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
-                pack(acc[1]); KEMR_STORE_PASS(dA0, dA1, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
-                pack(acc[2]); KEMR_STORE_PASS(dA0, dA1, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
-                pack(acc[3]); KEMR_STORE_PASS(dA0, dA1, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
-                pack(acc[4]); KEMR_STORE_PASS(dA0, dA1, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
-                pack(acc[5]); KEMR_STORE_PASS(dA0, dA1, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
-                pack(acc[6]); KEMR_STORE_PASS(dA0, dA1, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
-                pack(acc[7]); KEMR_STORE_PASS(dA0, dA1, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
-                KEMR_STORE_PASS(dA0, dA1, 0);
+                pack(acc[1]); KEMR_STORE_PASS_(dA0, dA1, 0, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                pack(acc[2]); KEMR_STORE_PASS_(dA0, dA1, 0, 1); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                pack(acc[3]); KEMR_STORE_PASS_(dA0, dA1, 0, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                pack(acc[4]); KEMR_STORE_PASS_(dA0, dA1, 0, 1); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                pack(acc[5]); KEMR_STORE_PASS_(dA0, dA1, 0, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                pack(acc[6]); KEMR_STORE_PASS_(dA0, dA1, 0, 1); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                pack(acc[7]); KEMR_STORE_PASS_(dA0, dA1, 0, 0); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
+                KEMR_STORE_PASS_(dA0, dA1, 0, 1);
             } else if constexpr (RES) {
                 // VMEM order: L0 L1 L2 L3 | S0 L4 | S1 L5 | S2 L6 | S3 L7 | S4 | S5 | S6 | S7 (a pair = 2 loads, a pass = 2 stores)
                 KEMR_XLOAD(0); KEMR_XLOAD(1); KEMR_XLOAD(2); KEMR_XLOAD(3);
@@ -1100,17 +1104,18 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             pack(acc[0]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
             pack(acc[1]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
             KEMR_STORE_PASS(dA0, dA1, 6); pack(acc[2]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
-            KEMR_STORE_PASS(dB0, dB1, 6); pack(acc[3]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
+            KEMR_STORE_PASS_(dB0, dB1, 6, 1); pack(acc[3]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
             KEMR_STORE_PASS(dA0, dA1, 6); pack(acc[4]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
-            KEMR_STORE_PASS(dB0, dB1, 6); pack(acc[5]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
+            KEMR_STORE_PASS_(dB0, dB1, 6, 1); pack(acc[5]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
             KEMR_STORE_PASS(dA0, dA1, 6); pack(acc[6]); KEMR_LDS_PASS(dA0, dA1, 0, 1024);
-            KEMR_STORE_PASS(dB0, dB1, 6); pack(acc[7]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
+            KEMR_STORE_PASS_(dB0, dB1, 6, 1); pack(acc[7]); KEMR_LDS_PASS(dB0, dB1, 8192, 9216);
             KEMR_STORE_PASS(dA0, dA1, 6);
-            KEMR_STORE_PASS(dB0, dB1, 0);
+            KEMR_STORE_PASS_(dB0, dB1, 0, 1);
             }
             if (CONC && wr == 1) __builtin_amdgcn_s_barrier();
     #undef KEMR_LDS_PASS
     #undef KEMR_STORE_PASS
+    #undef KEMR_STORE_PASS_
     #undef KEMR_RES_ADD
     #undef KEMR_XLOAD
         }
