@@ -27,6 +27,7 @@ extern "C" {
  *   "gemm_flags"    [A/B] timing experiments of the persistent GEMM's diagnostic instantiation: 1 = drop the C stores, 4 = plain
  *                   instead of non-temporal stores, 64 (+ 32) = cycle stamps per barrier interval, 128 = whole-kernel clock
  *   "gemm_order"    tile order of the persistent GEMM: 0 = N fastest, else log2(column-group width) + 1 (default 3)
+ *   "gemm_grid"     cap on the persistent GEMM's grid = the CUs it may take (0 = one workgroup per CU, the default); results do not depend on it
  *   "gemm_conc"     both wave halves' epilogues in one barrier interval: 0 never, 1 always, 2 = QuickGELU epilogue only (default)
  *   "gemm_kl"       K loop of the persistent GEMM: 0 = eight 256-cycle barrier intervals per K-tile (the product loop),
  *                   [A/B] 1 = four of 512

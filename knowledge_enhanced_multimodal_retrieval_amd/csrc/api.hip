@@ -648,6 +648,7 @@ const DebugKnob* debug_knobs(int* n) {
         {"gemm_variant", &g_gemm_variant, 0, 9, 1u << 0 | 1u << 1 | 1u << 2 | 1u << 7 | 1u << 8},   // 0 auto, 1 = 128x128, 2 = 256x256, 7 = persistent, 8 = skinny (all product kernels, forced); 3 = staggered 256x256, 4-6, 9 = earlier generations: A/B builds
         {"gemm_flags", &g_gemm_dbg, 0, 255, 1u << 0},  // timing-experiment flags of the DBG instantiation (1 drop stores, 4 plain stores, 32 / 64 / 128 stamps): A/B builds
         {"gemm_order", &g_gemm_order, 0, 8, ~0u},     // gemm256u tile order (0 = N fastest, else log2(column-group width) + 1)
+        {"gemm_grid", &g_gemm_grid, 0, 1024, ~0u},    // tools: cap on the persistent GEMM's grid (0 = one workgroup per CU); results do not depend on it
         {"gemm_conc", &g_gemm_conc, 0, 2, ~0u},       // both wave halves' epilogues in one barrier interval: 0 never, 1 always, 2 = QuickGELU only
         {"gemm_kl", &g_gemm_kl, 0, 1, 1u << 0},       // 0 = eight 256-cycle barrier intervals per K-tile (the product loop), 1 = four of 512 (round-3 experiment): A/B builds
         {"attn_v", &g_attn_v, 0, 5, 1u << 0},         // 0 = the product kernel, 1..4 = attention_ab.hip: A/B builds

@@ -157,6 +157,7 @@ extern int g_attn_waves;    // attention.hip (tools)
 extern int g_attn_v;        // attention.hip: 0 = the product kernel; 1..4 = attention_ab.hip (A/B builds only)
 extern int g_gemm_kl;       // gemm256u: 0 = eight barrier intervals per K-tile (the product loop), 1 = the long-interval K loop (A/B builds only)
 extern int g_ln_nt;         // layernorm.hip: cache-hint level of the residual forms, 3 = the product kernel; 0 / 1 / 2 in A/B builds only
+extern int g_gemm_grid;     // tools: cap on the persistent GEMM's grid (0 = one workgroup per CU)
 extern int g_gemm_conc;     // gemm256u: both wave halves run their epilogues in the same barrier interval (0 never, 1 always, 2 = QuickGELU epilogue only)
 int gemm_read_stamps(unsigned* host_out, int n_words);
 int launch_gemm256u_simgmax(const bf16_t* q_panel, int nq, const bf16_t* g_panel, int ng, int kdim, int stride, float* out,

@@ -171,6 +171,7 @@ int g_gemm_variant = 0;
 int g_gemm_dbg = 0;
 int g_gemm_order = 3;
 int g_gemm_conc = 2;
+int g_gemm_grid = 0;       // tools: > 0 caps the persistent GEMM's grid (workgroups = CUs it may take); 0 = every CU
 // gemm256u K loop: 0 = eight 256-cycle barrier intervals per K-tile (round 2; the default), 1 = four of 512 (round 3 experiment:
 // half the hand-overs, but the W pieces of a K-tile then have ONE interval of flight before the wait that needs them -- their
 // region is read until two intervals before -- and the stall eats the gain: 402 -> 414 us on fc2, 106 -> 111 on out-proj, same

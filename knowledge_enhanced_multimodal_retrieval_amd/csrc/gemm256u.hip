@@ -1203,7 +1203,8 @@ static int launch256u_a(const GemmParams& p, hipStream_t stream) {
     }
     if (!gemm256u_fits(p, FP8 ? 1 : 2, EPI == EPI_BIAS_RESID_F32 ? 4 : 2)) KEMR_FAIL(KEMR_ERR_INVALID, "gemm256u: M=%d N=%d K=%d is beyond the persistent kernel's tile table / 32-bit tile offsets", p.M, p.N, p.K);
     const int tiles = ((p.M + 255) / 256) * (p.N / 256);
-    const int grid = tiles < num_cu ? tiles : num_cu;
+    int grid = tiles < num_cu ? tiles : num_cu;
+    if (g_gemm_grid > 0 && grid > g_gemm_grid && (tiles + g_gemm_grid - 1) / g_gemm_grid <= GEMM256U_MAX_TILES_PER_WG) grid = g_gemm_grid;
     GemmParams q = p;
     q.dbg = g_gemm_dbg;
     q.order = g_gemm_order;

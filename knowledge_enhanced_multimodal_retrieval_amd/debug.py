@@ -11,7 +11,7 @@ import ctypes as C
 
 from . import _lib
 
-KEYS = ("gemm_variant", "gemm_flags", "gemm_order", "gemm_conc", "gemm_kl", "attn_v", "attn_xcd", "attn_waves", "sim_lists", "ln_nt")
+KEYS = ("gemm_variant", "gemm_flags", "gemm_order", "gemm_grid", "gemm_conc", "gemm_kl", "attn_v", "attn_xcd", "attn_waves", "sim_lists", "ln_nt")
 
 
 def ab_variants() -> bool:

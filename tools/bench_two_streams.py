@@ -18,7 +18,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (random_weights, synthetic_ids)
-from knowledge_enhanced_multimodal_retrieval_amd import engine  # noqa: E402
+from knowledge_enhanced_multimodal_retrieval_amd import debug, engine  # noqa: E402
 from knowledge_enhanced_multimodal_retrieval_amd.config import ARCHS  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -115,7 +115,23 @@ def leg_alt255_text(n):          # the same with the texts on a third stream (an
     return (255 + 1501) * n
 
 
+def with_grid(fn, cap):         # the same leg with the persistent GEMM's grid capped (debug switch gemm_grid): two half-chip GEMMs side by side
+    def run(n):
+        debug.set("gemm_grid", cap)
+        try:
+            return fn(n)
+        finally:
+            debug.set("gemm_grid", 0)
+    return run
+
+
 legs = {"alt-255": leg_alt255, "alt-255+text": leg_alt255_text, "it-par-main": leg_it_par_main, "it-par-hi": leg_it_par_hi, "one": leg_one, "halves": leg_halves, "streams": leg_streams, "it-seq": leg_it_seq, "it-par": leg_it_par}
+legs["alt-255 grid128"] = with_grid(leg_alt255, 128)
+legs["streams grid128"] = with_grid(leg_streams, 128)
+legs["alt-255+text grid128"] = with_grid(leg_alt255_text, 128)
+legs["alt-255 grid192"] = with_grid(leg_alt255, 192)
+if len(sys.argv) > 3:
+    legs = {k: v for k, v in legs.items() if k in sys.argv[3].split(",")}
 res = {k: [] for k in legs}
 # results must not depend on the arrangement
 torch.cuda.synchronize()
