@@ -495,14 +495,17 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     // in-kernel stamps (DBG instantiation; wave 0 only): dbg & 64 = cycles per barrier interval of the K loop + epilogue,
     // + dbg & 32 = own work before three of the barriers, dbg & 128 alone = whole-kernel cycles and 100 MHz ticks
     unsigned st_prev = 0, st_slot[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const bool stamping = DBG && (p.dbg & 64) && wid == 0 && p.stamps;
+    // + dbg & 8: the stamps of wave 4 (the trailing half) instead of wave 0; + dbg & 16: the K-loop slots count only the FIRST K-tile of every tile
+    const int st_wave = (DBG && (p.dbg & 8)) ? 4 : 0;
+    bool st_count = true;
+    const bool stamping = DBG && (p.dbg & 64) && wid == st_wave && p.stamps;
     auto stamp = [&](int slot) {
         if constexpr (DBG) {
             if (stamping) {
                 unsigned long long tt;
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
                 const unsigned now = (unsigned)tt;
-                st_slot[slot] += now - st_prev;
+                if (st_count) st_slot[slot] += now - st_prev;
                 st_prev = now;
             }
         }
@@ -512,12 +515,12 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             if (stamping && (p.dbg & 32)) {
                 unsigned long long tt;
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
-                st_slot[slot] += (unsigned)tt - st_prev;
+                if (st_count) st_slot[slot] += (unsigned)tt - st_prev;
             }
         }
     };
     unsigned long long clk0 = 0, rt0 = 0;
-    const bool clocking = DBG && (p.dbg & (64 | 128)) && wid == 0 && p.stamps;
+    const bool clocking = DBG && (p.dbg & (64 | 128)) && wid == st_wave && p.stamps;
     if constexpr (DBG) {
         if (clocking) {
             asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk0), "=s"(rt0) :: "memory");
@@ -661,6 +664,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     auto ktile = [&](auto first_c, auto mid_c) {
         constexpr bool FIRST = decltype(first_c)::value;
         constexpr bool MID = decltype(mid_c)::value;
+        if constexpr (DBG) st_count = FIRST || !(p.dbg & 16);
         const unsigned buf_this = stage_lds + gpar * PBUF;
         const unsigned abuf_next = buf_lds + (gpar ^ 1) * PBUF;
         if constexpr (FP8) {
@@ -807,6 +811,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             for (int t = 1; t < nt; ++t) ktile(std::false_type{}, std::false_type{});
         }
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // asm MFMA result -> VALU read (>= 12 wait states)
+        st_count = true;
 
         if constexpr (SIM != 0) {
             // ---- scan: acc[mi][ni][r] = score(query wr*128 + mi*16 + lrow, candidate wc*64 + ni*16 + lq*4 + r of this gallery tile).
