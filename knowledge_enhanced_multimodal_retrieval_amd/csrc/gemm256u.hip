@@ -29,7 +29,9 @@
 //
 // vmcnt (loads, LDS-DMA and stores retire in order): the wait that closes K-tile g needs K-tile g+1 landed and may leave
 // W0(g+2) (2 pieces per lane) in flight: vmcnt(2), or vmcnt(0) when nothing was staged behind it.  The 16 stores of a
-// tile sit between W0(g+2) and A0(g+2) in that order, so they get one K-tile of time before a wait covers them.
+// tile sit between W1(g+2) and A0(g+2) in that order; since round 4 (PRE, at the K-tile schedule) the store epilogue issues
+// the next tile's A(1) pieces in front of them and the first K-tile's waits leave the stores in flight, so they get a K-tile
+// and a half before a wait covers them.
 // The next tile's 256 bias floats ride with its first W0 piece (wave 0) into the other half of a 2 x 1 KiB LDS area.
 //
 // Epilogue: 8 passes of 16 rows through LDS (acc -> act -> bf16 -> ds_write_b64, chunk-XOR swizzled -> ds_read_b128 -> one
@@ -85,6 +87,9 @@ template <int I> struct HookAt { static constexpr int value = I; };
 // launch (cdna guide T5, static form); 3 = the inverse of 0 (the LOAD interval at priority 1); 4 = static for waves 0-3.
 // Same box, interleaved builds, bench.py --steps 40 (profiles/r04_gemm_prio.txt): mode 0 GEMM class 31.82 ms per step (0.5255 of peak),
 // mode 2 31.24 (0.5355), mode 1 31.14 (0.5371): +1.55 % on the step.  Results do not depend on the mode.
+#ifndef KEMR_GEMM_PRESTAGE
+#define KEMR_GEMM_PRESTAGE 1   // the next tile's K-tile-1 A pieces are staged at the START of the store epilogue (see the K-tile schedule); 0 = in its first K-tile (rounds 1-3)
+#endif
 #ifndef KEMR_GEMM_STORE_MIX
 #define KEMR_GEMM_STORE_MIX 0      // C stores: 0 = all non-temporal (the product), 3 = every other 16-row pass as plain write-back stores, 4 = all plain (A/B)
 #endif
@@ -660,6 +665,14 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
     // One K-tile.  LDS-DMA per interval: L1 A0(g+1), L2 A1(g+1), L3 W0(g+2), L4 W1(g+2) [+ bias]; the wait that needs K-tile
     // g+1 complete sits at the end of M3 (in front of the barrier in front of M4, whose hooks read K-tile g+1) and leaves
     // W0(g+2) in flight.
+    // PRE (round 4): vmcnt retires in order, so a wait for a piece that was issued BEHIND a tile's 16 stores also waits for the stores'
+    // acknowledgements -- and every workgroup of the chip stores its tile at the same moment (stamps: the first K-tile's vmcnt(4) cost
+    // +150 .. +840 cycles per tile).  The store epilogue therefore stages the A pieces of the next tile's K-tile 1 (normally L1 / L2 of
+    // its first K-tile; their LDS region, the last K-tile's A half, is free behind that K-tile's M3) BEFORE its stores, the first K-tile
+    // skips them, and its two waits let the 16 stores stay in flight: W(1) is followed by 4 A pieces + 16 stores + W0(2) = 22
+    // operations, A(1) by 16 stores + W(2) = 20.  The next wait that covers the stores is K-tile 1's, fourteen intervals behind them.
+    constexpr bool PRE_OK = KEMR_GEMM_PRESTAGE && !LONGK && SIM == 0 && (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16);
+    bool pre = false;                              // this tile's first K-tile finds its A(1) pieces staged
     // MID: a K-tile in which no stream wraps (no bias piece either: that rides with a tile's first W piece).
     auto ktile = [&](auto first_c, auto mid_c) {
         constexpr bool FIRST = decltype(first_c)::value;
@@ -672,7 +685,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             const char* sb = smem + gpar * PBUF + b_off;
             ld_w8(w08, sb);
             ld_a8(sa);
-            stage_a(0, oa, abuf_next);
+            if (!(FIRST && PRE_OK && pre)) stage_a(0, oa, abuf_next);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w08[0]), "+v"(w08[1]), "+v"(af8[0]), "+v"(af8[1]), "+v"(af8[2]), "+v"(af8[3]) :: "memory");
             __builtin_amdgcn_s_barrier();
             stamp(0);
@@ -680,7 +693,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             __builtin_amdgcn_s_barrier();
             stamp(1);
             ld_w8(w18, sb + 4096);
-            stage_a(1, oa, abuf_next);
+            if (!(FIRST && PRE_OK && pre)) stage_a(1, oa, abuf_next);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w18[0]), "+v"(w18[1]) :: "memory");     // the reads are done in front of the barrier: W may be re-staged behind the next one
             __builtin_amdgcn_s_barrier();
             stamp(2);
@@ -694,11 +707,13 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             __builtin_amdgcn_s_barrier();
             stamp(4);
             quad8<1, 1, FIRST>(acc, af8, w18, one, nohook);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // W(g+1) landed (and everything older: a tile's stores); all waves agree on it at this barrier
+            if (FIRST && PRE_OK && pre) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // W(g+1) landed (and everything older: a tile's stores); all waves agree on it at this barrier
             __builtin_amdgcn_s_barrier();
             stamp(5);
             stage_w(ow1, buf_this + 3 * PHALF);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // the half's own A(g+1) pieces landed; W(g+2) stays in flight
+            if (FIRST && PRE_OK && pre) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // the half's own A(g+1) pieces landed; W(g+2) stays in flight
             if constexpr (!MID) stage_bias();
             __builtin_amdgcn_s_barrier();
             stamp(6);
@@ -729,7 +744,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             __builtin_amdgcn_s_barrier();
             stamp(3);
         } else {
-            stage_a(0, oa, abuf_next);
+            if (!(FIRST && PRE_OK && pre)) stage_a(0, oa, abuf_next);
             stamp_pre(10);
             __builtin_amdgcn_s_barrier();
             stamp(0);
@@ -737,7 +752,7 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             stamp_pre(11);
             __builtin_amdgcn_s_barrier();
             stamp(1);
-            stage_a(1, oa, abuf_next);
+            if (!(FIRST && PRE_OK && pre)) stage_a(1, oa, abuf_next);
             __builtin_amdgcn_s_barrier();
             stamp(2);
             if constexpr (MID) cluster<0, false>(acc, ak1, wk1, b4, hook_m2_mid);
@@ -748,12 +763,14 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             __builtin_amdgcn_s_barrier();
             stamp(4);
             cluster<1, FIRST>(acc, ak0, wk0, b4, hook_m3);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // W(g+1) landed (and everything older: a tile's stores); all waves agree on it at this barrier
+            if (FIRST && PRE_OK && pre) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // W(g+1) landed (and everything older: a tile's stores); all waves agree on it at this barrier
             __builtin_amdgcn_s_barrier();
             stamp(5);
             stage_w(ow1, buf_this + 3 * PHALF);
             stamp_pre(12);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // the half's own A(g+1) pieces landed; W(g+2) stays in flight
+            if (FIRST && PRE_OK && pre) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // the half's own A(g+1) pieces landed; W(g+2) stays in flight
             stamp_pre(13);
             if constexpr (!MID) stage_bias();
             __builtin_amdgcn_s_barrier();
@@ -971,6 +988,14 @@ __global__ __launch_bounds__(512, 2) void gemm256u_bf16_nt_kernel(const GemmPara
             // sits out the interval of the trailing half's last cluster, the trailing half takes its next staging interval alone
             // afterwards.  Each wave then has only its own 2 KiB area (single-buffered passes); two waves per SIMD interleave.
             if (CONC && wr == 0) __builtin_amdgcn_s_barrier();
+            if constexpr (PRE_OK) {                                              // (PRE above; the A stream points at K-tile 1 of the next tile since the last K-tile's M2)
+                if (!(DBG && (p.dbg & 1))) {
+                    const unsigned abuf_pre = buf_lds + (gpar ^ 1) * PBUF;
+                    stage_a(0, oa, abuf_pre);
+                    stage_a(1, oa, abuf_pre);
+                    pre = true;
+                }
+            }
             int el = lane;
             asm volatile("" : "+v"(el));
             const int erow = el & 15, eq = el >> 4;
