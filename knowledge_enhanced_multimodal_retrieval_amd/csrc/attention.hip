@@ -46,6 +46,17 @@ __device__ __forceinline__ bool attn_item(int xbatch, int& h, int& b) {
 // NTLOAD (round 4, the default): the q | k | v rows are read ONCE per launch (K / V by the one workgroup of their head, a Q row by one wave),
 // so they are loaded non-temporally and do not displace the attention output -- which the out-proj GEMM reads next -- from L2 / Infinity
 // Cache: vision launch 147.2 -> 144.6 us alone, 4.50 -> 4.43 ms per step in the chain, bit-identical (tools/bench_attention_ab.py 0:0,0:7).
+// Wave priority by phase (compile-time A/B, -DKEMR_ATTN_PRIO=n with tools/ab_build_flag.sh; 0 = none, the product): 1 = priority 1 for the
+// two MFMA phases (S^T, PV) of a query tile, 2 = priority 1 for the softmax phase between them.  Two workgroups share a CU, so a SIMD holds two
+// waves of different (image, head) items in unrelated phases.
+#ifndef KEMR_ATTN_PRIO
+#define KEMR_ATTN_PRIO 0
+#endif
+__device__ __forceinline__ void attn_prio(int mfma_phase) {
+    if constexpr (KEMR_ATTN_PRIO == 1) { if (mfma_phase) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+    if constexpr (KEMR_ATTN_PRIO == 2) { if (mfma_phase) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+}
+
 template <bool NT>
 __device__ __forceinline__ bf16x8 load_q8(const bf16_t* p) {
     if constexpr (NT) return __builtin_nontemporal_load((const bf16x8*)p);
@@ -167,6 +178,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
                     dst[j][kk] = *(const bf16x8*)(sK + ((g * G + j) * 16 + lrow) * 128 + (((kk * 4 + lq) ^ (lrow >> 1)) << 4));
         };
         load_group(0, kfr[0]);
+        attn_prio(1);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (g + 1 < NG && (g + 1) * G * 16 < T) load_group(g + 1, kfr[(g + 1) & 1]);
@@ -182,6 +194,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        attn_prio(0);
         stamp(1);                                       // S^T MFMAs + K reads (+ the wait for this tile's Q)
         // s[t][r] = S[query lrow][key t*16 + lq*4 + r]
         float mx = -INFINITY;
@@ -236,6 +249,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
             }
         };
         load_v(0, vfr[0]);
+        attn_prio(1);
         // a block that is all pad keys, or (causal) all behind the diagonal, has P = 0 and is skipped (uniform); the live blocks are a prefix
         auto live = [&](int u) { return u < NT32 && u * 32 < T && !(CAUSAL && u * 32 > qt * 16 + 15); };
 #pragma unroll
@@ -253,6 +267,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[u & 1][dt], pf.v, o[dt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        attn_prio(0);
         stamp(4);                                       // PV MFMAs + V reads + P packing
         float sum = sum2.x + sum2.y;
         sum += __shfl_xor(sum, 16);
