@@ -22,6 +22,14 @@
 //    stream enters it, and hands them down (W -> A -> epilogue).
 // fp8 operands keep the round-1 clusters (one K = 128 MFMA per K-tile has no k halves to split) on the same staging plan.
 //
+// Round 4 (A/Bs in profiles/r04_gemm_prio.txt, stamps in profiles/r04_gemm_stamps.txt): what the wave in its load interval issues comes out of
+// its SIMD partner's MFMA cluster, so the K loop's load intervals now hold no vector-ALU instruction and no priority change -- no s_setprio
+// flips (KEMR_GEMM_PRIO), the stream offsets in the scalar base of the LDS-DMA pieces (KEMR_GEMM_SBASE), the LDS-buffer flips as asm inside
+// MFMA gaps (KEMR_GEMM_FLIPASM), the streams' wrap arithmetic only in the K-tiles that can wrap (KEMR_GEMM_MID) -- and the next tile's first A
+// pieces are staged in front of the store epilogue so that no wait of its first K-tile covers the stores (KEMR_GEMM_PRESTAGE): GEMM class
+// 0.5255 -> 0.545-0.553 of the bf16 peak, MFMA pipe busy 66.9 -> 72.6 %, results unchanged.  What remains is the tile boundary (every workgroup of
+// the chip stores its tile at the same moment: 9 % of a K = 1024 launch) and the clock (1.75-1.90 GHz under the kernel).
+//
 // LDS regions and who reads them: a wave reads W from the half that holds its 64 columns (in L1 and L2) and A from its own
 // row half (L1-L3); a region may be re-staged once BOTH wave halves are past their last read of it and have waited for the
 // data (the lgkmcnt(0) in front of the next cluster) and a barrier lies in between: W0 of this K-tile's buffer from the
